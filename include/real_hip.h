@@ -1,0 +1,181 @@
+/*
+ * real_hip.h -- C ABI of the MI355X (gfx950) read-matching hot path of REAL.
+ *
+ * The reference (solonas13/REAL) has no plugin / FFI interface: the hot path
+ * sits behind C++ template seams inside one binary.  This
+ * header is the drop-in boundary a maintainer would bind instead of the
+ * per-read loops
+ *
+ *     for z in block: UM.match(pattern, uniqueinfo[patid], fi, RWB, handled)
+ *                                   matchUniqueImplementation.cpp:1268-1295
+ *     for z in block: AM.match(pattern, fi, RWB, handled, localmatches);
+ *                     unifyMatches(localmatches)
+ *                                   matchAllImplementation.cpp:459-533
+ *
+ * Plain pointers and sizes only; no C++ / torch types; nothing throws across
+ * the boundary: every entry point returns 0 or a negative real_hip_status.
+ * Each entry point cites the reference interface it replaces.
+ *
+ * Threading: one submitting thread per ctx (calls on one ctx are not
+ * re-entrant); distinct ctx (one per GPU) are independent.
+ */
+#ifndef REAL_HIP_H
+#define REAL_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define REAL_HIP_ABI_VERSION 1
+
+typedef struct real_hip_ctx real_hip_ctx;
+
+typedef enum real_hip_status {
+    REAL_HIP_OK            =  0,
+    REAL_HIP_E_INVALID     = -1,  /* bad argument / struct_size                       */
+    REAL_HIP_E_NOMEM       = -2,  /* host or device allocation failed (std::bad_alloc
+                                     in the reference, matchUniqueImplementation.cpp:1215-1219) */
+    REAL_HIP_E_DEVICE      = -3,  /* HIP runtime error (see real_hip_last_error)      */
+    REAL_HIP_E_OVERFLOW    = -4,  /* output capacity too small; *n_out = needed size  */
+    REAL_HIP_E_STATE       = -5,  /* text / index not set                             */
+    REAL_HIP_E_UNSUPPORTED = -6   /* e.g. read longer than REAL_HIP_MAX_PATL          */
+} real_hip_status;
+
+#define REAL_HIP_MAX_PATL 256u   /* longest read the kernels hold in registers */
+
+/* ---- parameters: what RealOptions (RealOptions.hpp:27-77) hands the matcher */
+typedef struct real_hip_params {
+    uint32_t struct_size;   /* = sizeof(real_hip_params)                              */
+    uint32_t seedl;         /* -l : 4..64, multiple of 4 (RealOptions.cpp:434-447)    */
+    uint32_t seedkmax;      /* -s : <= 2 (RealOptions.cpp:449-453)                    */
+    uint32_t totalkmax;     /* -e : <= 15 (RealOptions.cpp:172-180)                   */
+    uint32_t scores;        /* -q : 0/1                                               */
+    uint32_t prefix_bits;   /* device bucket-table width; 0 = auto from index size.
+                               (The reference's 22-bit getSampleBits() table is a
+                               host-layout detail; results do not depend on it.)      */
+    int32_t  device;        /* HIP device ordinal                                     */
+    uint32_t reserved;
+    double   filter_mult;   /* RealOptions.cpp:455-463; epsilon=(float)(filter_mult*patl),
+                               RealOptions.hpp:74-77, matchUniqueImplementation.cpp:405 */
+    double   LL[1024];      /* Scoring::getRawLogScoreTable, index (ref<<8)|(read<<6)|q
+                               (Scoring.hpp:70-73); ignored if !scores                */
+} real_hip_params;
+
+/* Scoring::init + getScore (Scoring.cpp:61-133,155-171): fills LL for the
+ * -similarity -gc -trans -err -gcmut_bias flags; host-side helper.            */
+void real_hip_scoring_table(double similarity, double gc, double trans, double err,
+                            double gcmut_bias, double LL[1024]);
+
+int  real_hip_create(real_hip_ctx **out, const real_hip_params *p);
+void real_hip_destroy(real_hip_ctx *ctx);
+const char *real_hip_strerror(int status);
+const char *real_hip_last_error(const real_hip_ctx *ctx);
+int  real_hip_abi_version(void);
+
+/* ---- genome text: replaces what getText<sse4>() + RangeVector hand the
+ * matcher (getText.hpp:31-55, AutoTextArray.hpp:63-109, RangeVector.hpp:46-58).
+ * text2bit: 2 bits/base, base i at bits 63-2(i%32)-1.. of word i/32 (MSB
+ * first, N stored as 0); wildbits: bit i (MSB first) set iff base i is N;
+ * frag_start[n_frag] = n_bases ("terminal", countReads.cpp:81).  Host pointers;
+ * copied to HBM.                                                              */
+int real_hip_set_text(real_hip_ctx *ctx, uint32_t fileid,
+                      const uint64_t *text2bit, const uint64_t *wildbits, uint64_t n_bases,
+                      const uint64_t *frag_start, uint32_t n_frag);
+/* same from mapped symbols 0..4 (countReads.cpp:83-125 readFile); packed on
+ * the device.  sym_on_device != 0: sym is a device pointer.                   */
+int real_hip_set_text_symbols(real_hip_ctx *ctx, uint32_t fileid,
+                              const uint8_t *sym, uint64_t n_bases, int sym_on_device,
+                              const uint64_t *frag_start, uint32_t n_frag);
+
+/* ---- genome index block: what ListSetBlockReader::readNextBlock() exposes
+ * (ListSetBlockReader.hpp:24-52, ListSet.hpp:23-31).
+ * Host-built form: six lists in the host's sorted order (stable => ascending
+ * position inside equal signatures); sign[k] has n_entries elements of
+ * sig_bytes (4 if seedl <= 32 else 8, real.cpp:219-229); pos[k][j] = window
+ * start of entry j (Mask::getPos, Mask.hpp:36-40,55-59).                      */
+int real_hip_set_index_block(real_hip_ctx *ctx, uint64_t n_entries,
+                             const void *const sign[6], const uint32_t *const pos[6]);
+/* Device-built form: enumerates the N-free windows
+ * [first_window, first_window+max_entries) of the resident text
+ * (MapTextFile.hpp:118-230), sorts the six lists on the GPU.  Same device
+ * arrays as the host-built form.                                              */
+int real_hip_build_index_block(real_hip_ctx *ctx, uint64_t first_window, uint64_t max_entries,
+                               uint64_t *n_entries, int *have_next);
+/* introspection (tests, CPU baseline): device layout of list k               */
+int real_hip_index_info(const real_hip_ctx *ctx, uint64_t *n_entries, uint32_t *prefix_bits);
+int real_hip_index_download(real_hip_ctx *ctx, int list, uint32_t *fingerprint, uint32_t *pos,
+                            uint32_t *bucket_start /* 2^prefix_bits + 1 */);
+
+/* ---- read batch: a decoded pattern block (PatternBlock / FastSubDecoder::
+ * fillPatternBlock, FastSubDecoder.hpp:107-161): mapped symbols A,C,G,T->0..3,
+ * other->4 (acgtnMap.hpp:39-50) and quality = ASCII - offset in 0..63.        */
+typedef struct real_hip_batch {
+    uint32_t        struct_size;
+    uint32_t        on_device;  /* 0: all pointers of the call are host memory (copied);
+                                   1: all are device pointers (bases, qual, offsets and the
+                                      info / score / hit outputs)                         */
+    uint64_t        n_reads;
+    const uint8_t  *bases;      /* concatenated mapped symbols                          */
+    const uint8_t  *qual;       /* concatenated qualities; NULL => 30 (Pattern.hpp:42-45) */
+    const uint64_t *offsets;    /* n_reads+1 start offsets; NULL => uniform length patl  */
+    uint32_t        patl;       /* uniform read length if offsets == NULL               */
+    uint32_t        max_patl;   /* upper bound of read length when offsets != NULL and
+                                   on_device (0: library computes it)                   */
+} real_hip_batch;
+
+/* matchUnique: replaces the loop over UniqueMatcher::match
+ * (matchUniqueImplementation.cpp:369-500) including the best/unique fold
+ * UpdateUniqueInfo<scores>::update (:97-160, :179-248).  info[i] is the 64-bit
+ * UniqueMatchInfo record {state:3@61, fragment:16@45, errors:4@41, fileid:6@35,
+ * pos:35@0} (UniqueMatchInfo.hpp:29-39), score[i] its float (init -FLT_MAX,
+ * :191); both in/out so folds compose across genome blocks and files exactly
+ * as uniqueinfo[] does (matchUniqueImplementation.cpp:1094-1097).  Reads
+ * shorter than seedl or containing a symbol > 3 are skipped (:376-394).
+ * score may be NULL iff !scores.  Synchronous on return.                      */
+int real_hip_match_unique(real_hip_ctx *ctx, const real_hip_batch *b,
+                          uint64_t *info, float *score);
+
+/* matchAll: replaces AllMatcher::match + unifyMatches
+ * (matchAllImplementation.cpp:261-355, :150-161) for the resident block.      */
+typedef struct real_hip_hit {       /* MatchPosAndError, matchAllImplementation.cpp:99-120 */
+    uint32_t read;                  /* index inside the batch                              */
+    uint32_t pos;                   /* 0-based position in the text of fileid              */
+    float    score;                 /* 1.0f if !scores (ComputeScore.hpp:31-45)            */
+    uint16_t frag;
+    uint8_t  k;                     /* mismatches                                          */
+    uint8_t  inverted;              /* 0 '+', 1 '-'                                        */
+} real_hip_hit;
+/* out[hit_offsets[i] .. hit_offsets[i+1]) = hits of read i in unifyMatches order
+ * (k, pos, file, frag, score, inverted; duplicates removed).  cap = capacity of
+ * out; on REAL_HIP_E_OVERFLOW *n_out is the size needed.  hit_offsets has
+ * n_reads+1 entries (may be NULL).                                            */
+int real_hip_match_all(real_hip_ctx *ctx, const real_hip_batch *b,
+                       real_hip_hit *out, uint64_t cap, uint64_t *n_out, uint64_t *hit_offsets);
+
+/* ---- work counters: accumulated since the last reset ---------- */
+typedef struct real_hip_counters {
+    uint64_t reads;       /* R  reads matched (not skipped)                           */
+    uint64_t lookups;     /* L  ::match calls (12 per read, 7 with the uni0 early-out) */
+    uint64_t probes;      /* P  index entries examined inside the buckets             */
+    uint64_t candidates;  /* C  entries of the reference's equal range                */
+    uint64_t seedpass;    /* S  candidates with seedk <= seedkmax                     */
+    uint64_t hits;        /* H  updater::update calls                                 */
+    uint64_t verified;    /* distinct (read,strand,pos) actually verified on text     */
+    uint64_t reserved;
+} real_hip_counters;
+int real_hip_counters_get(real_hip_ctx *ctx, real_hip_counters *out, int reset);
+
+/* ---- timing: HIP events recorded on the ctx's own stream around every kernel
+ * of the path; times are accumulated per kernel since the last reset.         */
+enum { REAL_HIP_K_PACK = 0, REAL_HIP_K_MATCH_UNIQUE = 1, REAL_HIP_K_MATCH_ALL = 2,
+       REAL_HIP_K_ALL_SORT = 3, REAL_HIP_K_INDEX = 4, REAL_HIP_K_COUNT = 5 };
+int real_hip_kernel_time(real_hip_ctx *ctx, int which, double *total_ms, uint64_t *launches, int reset);
+int real_hip_timing_enable(real_hip_ctx *ctx, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,357 @@
+// index_build.hip -- device-resident genome text and index.
+//
+//   * text packing: AutoTextArray's layout (AutoTextArray.hpp:28-61) from mapped symbols;
+//   * index layout: each of the reference's six sorted lists (ListSet.hpp:23-31,
+//     Mask.hpp:22-64) becomes an array of {fingerprint, position} in the same order,
+//     plus a table of bucket starts keyed by the top `pb` signature bits.  `ptr`
+//     and the partner list are not needed on the device: list_b[p->ptr].sign is
+//     the other two seed segments of the same text window and is re-read from the
+//     2-bit text at `pos`;
+//   * device index build: window enumeration (MapTextFile.hpp:118-230),
+//     six stable LSD radix sorts (rocPRIM; the index build is outside the hot path)
+//     and the bucket tables;
+//   * the matchAll post-pass (per-read ordering of unifyMatches,
+//     matchAllImplementation.cpp:122-161).
+#include "real_hip_internal.h"
+
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+
+// ---------------------------------------------------------------------------
+// text
+// ---------------------------------------------------------------------------
+__global__ void pack_text_kernel(const uint8_t *__restrict__ sym, uint64_t n, uint64_t *__restrict__ text,
+                                 uint64_t *__restrict__ wild, unsigned long long *n_wild)
+{
+    uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; // one wildcard word = 64 symbols
+    uint64_t base = w * 64;
+    if (base >= n) return;
+    uint64_t t0 = 0, t1 = 0, wd = 0;
+    for (int b = 0; b < 64; ++b) {
+        uint64_t i = base + b;
+        if (i < n) {
+            uint64_t c = sym[i];
+            if (c > 3) wd |= 1ull << (63 - b); // writeBit(utext[i] > 3)
+            c &= 3;                              // writer.write(utext[i] & 0x3, 2)
+            if (b < 32) t0 |= c << (62 - 2 * b); else t1 |= c << (62 - 2 * (b - 32));
+        }
+    }
+    text[2 * w] = t0;
+    text[2 * w + 1] = t1; // buffers are padded, 2w+1 is always inside
+    wild[w] = wd;
+    if (wd) atomicAdd(n_wild, (unsigned long long)__popcll(wd));
+}
+
+__global__ void count_wild_kernel(const uint64_t *__restrict__ wild, uint64_t nw, unsigned long long *n_wild)
+{
+    uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < nw && wild[w]) atomicAdd(n_wild, (unsigned long long)__popcll(wild[w]));
+}
+
+int rh_pack_text(real_hip_ctx *ctx, const uint8_t *d_sym, uint64_t n)
+{
+    uint64_t nw = (n + 63) / 64;
+    unsigned long long *d_cnt = (unsigned long long *)ctx->counters.p + 8; // scratch slot
+    RH_HIP(ctx, hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
+    if (nw)
+        hipLaunchKernelGGL(pack_text_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, ctx->stream, d_sym, n,
+                           (uint64_t *)ctx->text.p, (uint64_t *)ctx->wild.p, d_cnt);
+    RH_HIP(ctx, hipGetLastError());
+    unsigned long long h = 0;
+    RH_HIP(ctx, hipMemcpyAsync(&h, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
+    RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->n_wild = h;
+    return REAL_HIP_OK;
+}
+
+int rh_count_wild(real_hip_ctx *ctx, uint64_t n)
+{
+    uint64_t nw = (n + 63) / 64;
+    unsigned long long *d_cnt = (unsigned long long *)ctx->counters.p + 8;
+    RH_HIP(ctx, hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
+    if (nw)
+        hipLaunchKernelGGL(count_wild_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const uint64_t *)ctx->wild.p, nw, d_cnt);
+    unsigned long long h = 0;
+    RH_HIP(ctx, hipMemcpyAsync(&h, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
+    RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->n_wild = h;
+    return REAL_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// index layout from a sorted list
+// ---------------------------------------------------------------------------
+uint32_t rh_choose_prefix_bits(const real_hip_ctx *ctx, uint64_t n_entries)
+{
+    uint32_t l = ctx->prm.seedl;
+    uint32_t pb = ctx->prm.prefix_bits;
+    if (!pb) { // auto: mean bucket of 4..8 entries, at most 2^28 buckets (1 GiB of starts per list)
+        uint32_t lg = 0;
+        while ((1ull << (lg + 1)) <= (n_entries ? n_entries : 1)) lg++;
+        pb = lg > 2 ? lg - 2 : 1;
+        if (pb < 8) pb = 8;
+        if (pb > 28) pb = 28;
+    }
+    if (pb > l) pb = l; // a signature has seedl bits (two segments of seedl/4 bases)
+    if (pb > 30) pb = 30;
+    if (pb < 1) pb = 1;
+    return pb;
+}
+
+template <typename K>
+__global__ void entries_kernel(const K *__restrict__ sign, const uint32_t *__restrict__ pos, uint64_t n, uint32_t pshift,
+                               uint32_t fshift, uint32_t nbuckets, uint2 *__restrict__ ent, uint32_t *__restrict__ bkt)
+{
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    uint64_t s = (uint64_t)sign[j];
+    ent[j] = make_uint2((uint32_t)(s >> fshift), pos[j]);
+    uint32_t p = (uint32_t)(s >> pshift);
+    int64_t pprev = j ? (int64_t)(uint32_t)((uint64_t)sign[j - 1] >> pshift) : -1;
+    // bucket q starts at the first entry whose prefix is >= q (getLookupTable.hpp:26-51 keeps
+    // [low,high) per prefix; consecutive starts carry the same information, empty = [x,x))
+    for (int64_t q = pprev + 1; q <= (int64_t)p; ++q) bkt[q] = (uint32_t)j;
+    if (j == n - 1)
+        for (uint64_t q = (uint64_t)p + 1; q <= nbuckets; ++q) bkt[q] = (uint32_t)n;
+}
+
+int rh_index_from_sorted(real_hip_ctx *ctx, int list, const void *d_sign, const uint32_t *d_pos, uint64_t n,
+                         unsigned sig_bytes)
+{
+    const uint32_t l = ctx->prm.seedl, pb = ctx->pb;
+    const uint32_t pshift = l - pb, fshift = (l > pb + 32) ? (l - pb - 32) : 0;
+    const uint32_t nb = 1u << pb;
+    int rc = rh_reserve(ctx, ctx->ent[list], (n ? n : 1) * sizeof(uint2));
+    if (rc) return rc;
+    rc = rh_reserve(ctx, ctx->bkt[list], ((size_t)nb + 1) * 4);
+    if (rc) return rc;
+    if (!n) {
+        RH_HIP(ctx, hipMemsetAsync(ctx->bkt[list].p, 0, ((size_t)nb + 1) * 4, ctx->stream));
+        return REAL_HIP_OK;
+    }
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (sig_bytes == 4)
+        hipLaunchKernelGGL(entries_kernel<uint32_t>, grid, block, 0, ctx->stream, (const uint32_t *)d_sign, d_pos, n, pshift,
+                           fshift, nb, (uint2 *)ctx->ent[list].p, (uint32_t *)ctx->bkt[list].p);
+    else
+        hipLaunchKernelGGL(entries_kernel<uint64_t>, grid, block, 0, ctx->stream, (const uint64_t *)d_sign, d_pos, n, pshift,
+                           fshift, nb, (uint2 *)ctx->ent[list].p, (uint32_t *)ctx->bkt[list].p);
+    RH_HIP(ctx, hipGetLastError());
+    return REAL_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// device index build
+// ---------------------------------------------------------------------------
+// window [i,i+l) is emitted iff it holds no N (MapTextFile::readNextSignature /
+// readFullSignature, MapTextFile.hpp:118-179); fragment boundaries do not cut windows.
+__global__ void window_flags_kernel(const uint64_t *__restrict__ wild, uint64_t nwin, uint32_t l, uint8_t *__restrict__ flags)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nwin) return;
+    uint64_t a = i, e = i + l - 1, wa = a >> 6, we = e >> 6;
+    bool ok = true;
+    for (uint64_t w = wa; w <= we; ++w) {
+        uint64_t m = ~0ull;
+        if (w == wa) m &= ~0ull >> (a & 63);
+        if (w == we) m &= ~0ull << (63 - (e & 63));
+        if (wild[w] & m) ok = false;
+    }
+    flags[i] = ok ? 1 : 0;
+}
+
+__global__ void iota_kernel(uint32_t *out, uint64_t first, uint64_t n)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (uint32_t)(first + i);
+}
+
+__device__ __forceinline__ uint64_t dev_text_bits(const uint64_t *__restrict__ T, uint64_t i, unsigned nb)
+{
+    uint64_t w = i >> 5;
+    unsigned sh = 2u * (unsigned)(i & 31);
+    uint64_t v = T[w] << sh;
+    if (sh + 2 * nb > 64) v |= T[w + 1] >> (64 - sh);
+    return v >> (64 - 2 * nb);
+}
+
+// list k signature of the window at wpos[j] (MapTextFile::readLists, MapTextFile.hpp:211-216)
+template <typename K>
+__global__ void keys_kernel(const uint64_t *__restrict__ T, const uint32_t *__restrict__ wpos, uint64_t n, uint32_t l,
+                            int list, K *__restrict__ keys)
+{
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t q = l >> 2, bb = 2 * q;
+    const int sa_seg = (list < 3) ? 0 : (list < 5) ? 1 : 2;
+    const int sc_seg = (list == 0) ? 1 : (list == 1 || list == 3) ? 2 : 3;
+    uint64_t p = wpos[j];
+    uint64_t ma = dev_text_bits(T, p + (uint64_t)sa_seg * q, q);
+    uint64_t mc = dev_text_bits(T, p + (uint64_t)sc_seg * q, q);
+    keys[j] = (K)((ma << bb) | mc);
+}
+
+template <typename K>
+static int sort_list(real_hip_ctx *ctx, int list, const uint32_t *d_wpos, uint64_t n)
+{
+    const uint32_t l = ctx->prm.seedl;
+    int rc;
+    if ((rc = rh_reserve(ctx, ctx->keys_a, (n ? n : 1) * sizeof(K)))) return rc;
+    if ((rc = rh_reserve(ctx, ctx->keys_b, (n ? n : 1) * sizeof(K)))) return rc;
+    if ((rc = rh_reserve(ctx, ctx->vals_b, (n ? n : 1) * 4))) return rc;
+    if (n) {
+        hipLaunchKernelGGL(keys_kernel<K>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const uint64_t *)ctx->text.p, d_wpos, n, l, list, (K *)ctx->keys_a.p);
+        size_t tmp = 0;
+        RH_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp, (K *)ctx->keys_a.p, (K *)ctx->keys_b.p, d_wpos,
+                                              (uint32_t *)ctx->vals_b.p, (size_t)n, 0u, l, ctx->stream));
+        if ((rc = rh_reserve(ctx, ctx->sort_tmp, tmp ? tmp : 8))) return rc;
+        // stable LSD radix sort over the l signature bits: equal signatures keep ascending position,
+        // as the reference's ParallelRadixSort (ParallelRadixSort.hpp:160-203) does
+        RH_HIP(ctx, rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp, (K *)ctx->keys_a.p, (K *)ctx->keys_b.p, d_wpos,
+                                              (uint32_t *)ctx->vals_b.p, (size_t)n, 0u, l, ctx->stream));
+    }
+    return rh_index_from_sorted(ctx, list, ctx->keys_b.p, (const uint32_t *)ctx->vals_b.p, n, sizeof(K));
+}
+
+int rh_index_build_device(real_hip_ctx *ctx, uint64_t first_window, uint64_t max_entries, uint64_t *n_entries,
+                          int *have_next)
+{
+    RhTimer tm(ctx, REAL_HIP_K_INDEX);
+    const uint32_t l = ctx->prm.seedl;
+    const uint64_t n = ctx->n_bases;
+    const uint64_t nwin_all = (n >= l) ? (n - l + 1) : 0;
+    uint64_t total_valid = nwin_all;
+    const uint32_t *d_wpos = nullptr;
+    uint64_t cnt = 0;
+    int rc;
+    if (ctx->n_wild == 0) {
+        cnt = (first_window < nwin_all) ? (nwin_all - first_window) : 0;
+        if (cnt > max_entries) cnt = max_entries;
+        if ((rc = rh_reserve(ctx, ctx->vals_a, (cnt ? cnt : 1) * 4))) return rc;
+        if (cnt)
+            hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (uint32_t *)ctx->vals_a.p, first_window, cnt);
+        d_wpos = (const uint32_t *)ctx->vals_a.p;
+    } else {
+        // flags -> compacted ascending window starts (all blocks), then slice
+        DevBuf flags, sel, dcount;
+        if ((rc = rh_reserve(ctx, flags, nwin_all ? nwin_all : 1))) return rc;
+        if ((rc = rh_reserve(ctx, ctx->vals_a, (nwin_all ? nwin_all : 1) * 4))) { rh_release(flags); return rc; }
+        if ((rc = rh_reserve(ctx, dcount, 8))) { rh_release(flags); return rc; }
+        RH_HIP(ctx, hipMemsetAsync(dcount.p, 0, 8, ctx->stream));
+        if (nwin_all) {
+            hipLaunchKernelGGL(window_flags_kernel, dim3((unsigned)((nwin_all + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (const uint64_t *)ctx->wild.p, nwin_all, l, (uint8_t *)flags.p);
+            size_t tmp = 0;
+            RH_HIP(ctx, rocprim::select(nullptr, tmp, rocprim::counting_iterator<uint32_t>(0), (uint8_t *)flags.p,
+                                        (uint32_t *)ctx->vals_a.p, (size_t *)dcount.p, (size_t)nwin_all, ctx->stream));
+            if ((rc = rh_reserve(ctx, sel, tmp ? tmp : 8))) { rh_release(flags); rh_release(dcount); return rc; }
+            RH_HIP(ctx, rocprim::select(sel.p, tmp, rocprim::counting_iterator<uint32_t>(0), (uint8_t *)flags.p,
+                                        (uint32_t *)ctx->vals_a.p, (size_t *)dcount.p, (size_t)nwin_all, ctx->stream));
+        }
+        size_t hcount = 0;
+        RH_HIP(ctx, hipMemcpyAsync(&hcount, dcount.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+        RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        rh_release(flags); rh_release(sel); rh_release(dcount);
+        total_valid = hcount;
+        cnt = (first_window < total_valid) ? (total_valid - first_window) : 0;
+        if (cnt > max_entries) cnt = max_entries;
+        d_wpos = (const uint32_t *)ctx->vals_a.p + first_window;
+    }
+    ctx->n_entries = cnt;
+    ctx->pb = rh_choose_prefix_bits(ctx, cnt);
+    for (int k = 0; k < 6; ++k) {
+        rc = (l <= 32) ? sort_list<uint32_t>(ctx, k, d_wpos, cnt) : sort_list<uint64_t>(ctx, k, d_wpos, cnt);
+        if (rc) return rc;
+    }
+    RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // the sort workspace is large (4 arrays of n); give it back
+    rh_release(ctx->keys_a); rh_release(ctx->keys_b); rh_release(ctx->vals_a); rh_release(ctx->vals_b);
+    rh_release(ctx->sort_tmp);
+    ctx->have_index = true;
+    if (n_entries) *n_entries = cnt;
+    if (have_next) *have_next = (first_window + cnt < total_valid) ? 1 : 0;
+    return REAL_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// matchAll post-pass: order the raw hit records per read as unifyMatches does
+// (operator<, matchAllImplementation.cpp:122-136: k, pos, file, frag, score, inverted;
+// file is constant inside a call and frag is a monotone function of pos).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t float_order(uint32_t b) { return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+
+__global__ void all_keys_lo_kernel(const uint4 *__restrict__ raw, uint64_t n, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint4 h = raw[i];
+    uint32_t inv = (h.w >> 8) & 1;
+    keys[i] = ((uint64_t)(h.y & 15) << 33) | ((uint64_t)float_order(h.z) << 1) | inv;
+    vals[i] = (uint32_t)i;
+}
+__global__ void all_keys_hi_kernel(const uint4 *__restrict__ raw, const uint32_t *__restrict__ vals, uint64_t n,
+                                   uint64_t *__restrict__ keys)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint4 h = raw[vals[i]];
+    keys[i] = ((uint64_t)h.x << 32) | ((uint64_t)(h.w & 15) << 28) | (uint64_t)(h.y >> 4);
+}
+__global__ void all_gather_kernel(const uint4 *__restrict__ raw, const uint32_t *__restrict__ vals, uint64_t n,
+                                  real_hip_hit *__restrict__ out)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint4 h = raw[vals[i]];
+    real_hip_hit o;
+    o.read = h.x; o.pos = h.y; o.score = __uint_as_float(h.z);
+    o.frag = (uint16_t)(h.w >> 16); o.k = (uint8_t)(h.w & 0xff); o.inverted = (uint8_t)((h.w >> 8) & 1);
+    out[i] = o;
+}
+// hit_offsets[r] = first sorted hit whose read >= r
+__global__ void all_offsets_kernel(const real_hip_hit *__restrict__ hits, uint64_t n_hits, uint64_t n_reads,
+                                   uint64_t *__restrict__ off)
+{
+    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n_reads) return;
+    uint64_t lo = 0, hi = n_hits;
+    while (lo < hi) {
+        uint64_t mid = lo + ((hi - lo) >> 1);
+        if ((uint64_t)hits[mid].read < r) lo = mid + 1; else hi = mid;
+    }
+    off[r] = lo;
+}
+
+int rh_all_finish(real_hip_ctx *ctx, uint64_t n_raw, uint64_t n_reads, real_hip_hit *d_out, uint64_t *d_hit_offsets)
+{
+    RhTimer tm(ctx, REAL_HIP_K_ALL_SORT);
+    int rc;
+    if (n_raw) {
+        if ((rc = rh_reserve(ctx, ctx->keys_a, n_raw * 8))) return rc;
+        if ((rc = rh_reserve(ctx, ctx->keys_b, n_raw * 8))) return rc;
+        if ((rc = rh_reserve(ctx, ctx->vals_a, n_raw * 4))) return rc;
+        if ((rc = rh_reserve(ctx, ctx->vals_b, n_raw * 4))) return rc;
+        dim3 grid((unsigned)((n_raw + 255) / 256)), block(256);
+        const uint4 *raw = (const uint4 *)ctx->raw.p;
+        uint64_t *ka = (uint64_t *)ctx->keys_a.p, *kb = (uint64_t *)ctx->keys_b.p;
+        uint32_t *va = (uint32_t *)ctx->vals_a.p, *vb = (uint32_t *)ctx->vals_b.p;
+        hipLaunchKernelGGL(all_keys_lo_kernel, grid, block, 0, ctx->stream, raw, n_raw, ka, va);
+        size_t tmp = 0;
+        RH_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp, ka, kb, va, vb, (size_t)n_raw, 0u, 64u, ctx->stream));
+        if ((rc = rh_reserve(ctx, ctx->sort_tmp, tmp ? tmp : 8))) return rc;
+        RH_HIP(ctx, rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp, ka, kb, va, vb, (size_t)n_raw, 0u, 37u, ctx->stream));
+        hipLaunchKernelGGL(all_keys_hi_kernel, grid, block, 0, ctx->stream, raw, vb, n_raw, ka);
+        RH_HIP(ctx, rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp, ka, kb, vb, va, (size_t)n_raw, 0u, 64u, ctx->stream));
+        hipLaunchKernelGGL(all_gather_kernel, grid, block, 0, ctx->stream, raw, va, n_raw, d_out);
+    }
+    if (d_hit_offsets)
+        hipLaunchKernelGGL(all_offsets_kernel, dim3((unsigned)((n_reads + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const real_hip_hit *)d_out, n_raw, n_reads, d_hit_offsets);
+    RH_HIP(ctx, hipGetLastError());
+    return REAL_HIP_OK;
+}

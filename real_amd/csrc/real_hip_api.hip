@@ -1,0 +1,499 @@
+// real_hip_api.hip -- the C ABI of include/real_hip.h: context, uploads, staging,
+// launches.  No CPU fallback: every entry point either runs the HIP path or fails.
+#include "real_hip_internal.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+int rh_count_wild(real_hip_ctx *ctx, uint64_t n);
+
+// ---------------------------------------------------------------------------
+// plumbing
+// ---------------------------------------------------------------------------
+int rh_fail(real_hip_ctx *ctx, int status, const char *what, hipError_t e)
+{
+    if (ctx) {
+        char buf[512];
+        snprintf(buf, sizeof buf, "%s: %s%s%s", real_hip_strerror(status), what, e != hipSuccess ? ": " : "",
+                 e != hipSuccess ? hipGetErrorString(e) : "");
+        ctx->last_error = buf;
+    }
+    (void)hipGetLastError(); // clear sticky state
+    return status;
+}
+
+int rh_reserve(real_hip_ctx *ctx, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return REAL_HIP_OK;
+    if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    hipError_t e = hipMalloc(&b.p, bytes);
+    if (e != hipSuccess) { b.p = nullptr; return rh_fail(ctx, REAL_HIP_E_NOMEM, "hipMalloc", e); }
+    b.cap = bytes;
+    return REAL_HIP_OK;
+}
+void rh_release(DevBuf &b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr; b.cap = 0;
+}
+
+RhTimer::RhTimer(real_hip_ctx *ctx, int w) : c(ctx), which(w)
+{
+    if (c->timing) (void)hipEventRecord(c->ev0, c->stream);
+}
+RhTimer::~RhTimer()
+{
+    if (!c->timing) return;
+    (void)hipEventRecord(c->ev1, c->stream);
+    if (hipEventSynchronize(c->ev1) == hipSuccess) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) { c->k_ms[which] += ms; c->k_n[which] += 1; }
+    }
+}
+
+extern "C" const char *real_hip_strerror(int s)
+{
+    switch (s) {
+    case REAL_HIP_OK: return "ok";
+    case REAL_HIP_E_INVALID: return "invalid argument";
+    case REAL_HIP_E_NOMEM: return "out of memory";
+    case REAL_HIP_E_DEVICE: return "HIP runtime error";
+    case REAL_HIP_E_OVERFLOW: return "output capacity too small";
+    case REAL_HIP_E_STATE: return "text or index not set";
+    case REAL_HIP_E_UNSUPPORTED: return "unsupported";
+    default: return "unknown status";
+    }
+}
+extern "C" const char *real_hip_last_error(const real_hip_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+extern "C" int real_hip_abi_version(void) { return REAL_HIP_ABI_VERSION; }
+
+// ---------------------------------------------------------------------------
+// scoring table: Scoring::init + Scoring::getScore(char,char,int)
+// (Scoring.cpp:28-36, 61-133, 155-171).  Plain IEEE double arithmetic in the
+// reference's operation order; built once on the host.
+// ---------------------------------------------------------------------------
+static const double kQPrb[65] = {
+    1.0000000, 0.7943282, 0.6309573, 0.5011872, 0.3981072, 0.3162278, 0.2511886, 0.1995262, 0.1584893, 0.1258925,
+    0.1000000, 0.0794328, 0.0630957, 0.0501187, 0.0398107, 0.0316228, 0.0251189, 0.0199526, 0.0158489, 0.0125893,
+    0.0100000, 0.0079433, 0.0063096, 0.0050119, 0.0039811, 0.0031623, 0.0025119, 0.0019953, 0.0015849, 0.0012589,
+    0.0010000, 0.0007943, 0.0006310, 0.0005012, 0.0003981, 0.0003162, 0.0002512, 0.0001995, 0.0001585, 0.0001259,
+    0.0001000, 0.0000794, 0.0000631, 0.0000501, 0.0000398, 0.0000316, 0.0000251, 0.0000200, 0.0000158, 0.0000126,
+    0.0000100, 0.0000079, 0.0000063, 0.0000050, 0.0000040, 0.0000032, 0.0000025, 0.0000020, 0.0000016, 0.0000013,
+    0.0000010, 0.0000008, 0.0000006, 0.0000005, 0.0000004};
+
+extern "C" void real_hip_scoring_table(double similarity, double gc, double trans, double err, double bias, double LL[1024])
+{
+    volatile double R[4][4]; // the reference stores every intermediate (-ffloat-store, src/Makefile.am:95-96)
+    volatile double t1 = trans * (1 - similarity);
+    volatile double t2 = (1 - trans) * (1 - similarity);
+    const double transit = t1, transver = t2;
+    double bg[4] = {(1 - gc) / 2, gc / 2, gc / 2, (1 - gc) / 2};
+    bias = bias * (1 - gc) / gc;
+    R[0][2] = transit / (bias + 1) / (1 - gc);
+    R[3][1] = transit / (bias + 1) / (1 - gc);
+    R[2][0] = transit / (bias + 1) / gc * bias;
+    R[1][3] = transit / (bias + 1) / gc * bias;
+    R[0][1] = transver / 2 / (bias + 1) / (1 - gc);
+    R[3][2] = transver / 2 / (bias + 1) / (1 - gc);
+    R[0][3] = transver / 2 / (bias + 1) / (1 - gc);
+    R[3][0] = transver / 2 / (bias + 1) / (1 - gc);
+    R[1][0] = transver / 2 / (bias + 1) / gc * bias;
+    R[2][3] = transver / 2 / (bias + 1) / gc * bias;
+    R[1][2] = transver / 2 / (bias + 1) / gc * bias;
+    R[2][1] = transver / 2 / (bias + 1) / gc * bias;
+    R[0][0] = 1 - R[0][1] - R[0][2] - R[0][3];
+    R[3][3] = 1 - R[3][0] - R[3][1] - R[3][2];
+    R[2][2] = 1 - R[2][0] - R[2][1] - R[2][3];
+    R[1][1] = 1 - R[1][0] - R[1][2] - R[1][3];
+    for (int x = 0; x < 4; ++x)
+        for (int y = 0; y < 4; ++y) {
+            R[x][y] *= 1 - err;
+            R[x][y] /= bg[y];
+        }
+    for (unsigned c0 = 0; c0 < 4; ++c0)
+        for (unsigned c1 = 0; c1 < 4; ++c1)
+            for (unsigned q = 0; q < 64; ++q)
+                LL[(c0 << 8) | (c1 << 6) | q] = std::log(R[c0][c1]) / std::log(2.0) * (1 - kQPrb[q]);
+}
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+extern "C" int real_hip_create(real_hip_ctx **out, const real_hip_params *p)
+{
+    if (!out || !p || p->struct_size != sizeof(real_hip_params)) return REAL_HIP_E_INVALID;
+    // RealOptions.cpp:434-453 clamps these; at the ABI they are errors
+    if (p->seedl < 4 || p->seedl > 64 || (p->seedl % 4) || p->seedkmax > 2 || p->totalkmax > 15) return REAL_HIP_E_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || p->device < 0 || p->device >= ndev) {
+        (void)hipGetLastError();
+        return REAL_HIP_E_DEVICE; // no GPU: the product path fails loudly, there is no CPU fallback
+    }
+    real_hip_ctx *c = new (std::nothrow) real_hip_ctx();
+    if (!c) return REAL_HIP_E_NOMEM;
+    c->prm = *p;
+    c->device = p->device;
+    int rc = REAL_HIP_OK;
+    do {
+        if (hipSetDevice(c->device) != hipSuccess) { rc = REAL_HIP_E_DEVICE; break; }
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = REAL_HIP_E_DEVICE; break; }
+        if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { rc = REAL_HIP_E_DEVICE; break; }
+        if ((rc = rh_reserve(c, c->LL, 1024 * sizeof(double)))) break;
+        if ((rc = rh_reserve(c, c->counters, 16 * sizeof(uint64_t)))) break;
+        if (hipMemcpy(c->LL.p, p->LL, 1024 * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { rc = REAL_HIP_E_DEVICE; break; }
+        if (hipMemset(c->counters.p, 0, 16 * sizeof(uint64_t)) != hipSuccess) { rc = REAL_HIP_E_DEVICE; break; }
+    } while (0);
+    if (rc) { real_hip_destroy(c); return rc; }
+    *out = c;
+    return REAL_HIP_OK;
+}
+
+extern "C" void real_hip_destroy(real_hip_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    DevBuf *all[] = {&c->text, &c->wild, &c->frag, &c->LL, &c->counters, &c->s_bases, &c->s_qual, &c->s_off, &c->s_info,
+                     &c->s_score, &c->words, &c->seeds, &c->qrows, &c->patl, &c->maxpatl, &c->raw, &c->raw_count, &c->keys_a,
+                     &c->keys_b, &c->vals_a, &c->vals_b, &c->sort_tmp, &c->hit_off, &c->s_hits};
+    for (DevBuf *b : all) rh_release(*b);
+    for (int k = 0; k < 6; ++k) { rh_release(c->ent[k]); rh_release(c->bkt[k]); }
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+#define RH_ENTER(ctx)                                   \
+    if (!(ctx)) return REAL_HIP_E_INVALID;              \
+    RH_HIP((ctx), hipSetDevice((ctx)->device));
+
+// ---------------------------------------------------------------------------
+// text
+// ---------------------------------------------------------------------------
+static int set_frag(real_hip_ctx *ctx, uint32_t fileid, uint64_t n, const uint64_t *frag_start, uint32_t n_frag)
+{
+    if (!frag_start || !n_frag || frag_start[0] != 0 || frag_start[n_frag] != n)
+        return rh_fail(ctx, REAL_HIP_E_INVALID, "frag_start must begin at 0 and end at n_bases", hipSuccess);
+    for (uint32_t i = 0; i < n_frag; ++i)
+        if (frag_start[i + 1] <= frag_start[i])
+            return rh_fail(ctx, REAL_HIP_E_INVALID, "fragment starts must be strictly increasing (empty FASTA records are not representable in the reference's RangeVector)", hipSuccess);
+    // UniqueMatchInfo.hpp:31-32: 6 bits of file id, 16 bits of fragment id; positions are u32
+    if (fileid >= 64 || n_frag > 65536 || n > 0xffffffffull)
+        return rh_fail(ctx, REAL_HIP_E_INVALID, "fileid/fragment/length exceeds the UniqueMatchInfo record", hipSuccess);
+    int rc = rh_reserve(ctx, ctx->frag, ((size_t)n_frag + 1) * 8);
+    if (rc) return rc;
+    RH_HIP(ctx, hipMemcpyAsync(ctx->frag.p, frag_start, ((size_t)n_frag + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->n_frag = n_frag; ctx->fileid = fileid; ctx->n_bases = n;
+    return REAL_HIP_OK;
+}
+
+static int alloc_text(real_hip_ctx *ctx, uint64_t n)
+{
+    // padded: kernels read one word past a window / write whole 64-symbol groups
+    size_t tw = (size_t)((n + 63) / 64) * 2 + 4, ww = (size_t)((n + 63) / 64) + 4;
+    int rc = rh_reserve(ctx, ctx->text, tw * 8);
+    if (rc) return rc;
+    if ((rc = rh_reserve(ctx, ctx->wild, ww * 8))) return rc;
+    RH_HIP(ctx, hipMemsetAsync(ctx->text.p, 0, tw * 8, ctx->stream));
+    RH_HIP(ctx, hipMemsetAsync(ctx->wild.p, 0, ww * 8, ctx->stream));
+    return REAL_HIP_OK;
+}
+
+extern "C" int real_hip_set_text(real_hip_ctx *ctx, uint32_t fileid, const uint64_t *text2bit, const uint64_t *wildbits,
+                                 uint64_t n, const uint64_t *frag_start, uint32_t n_frag)
+{
+    RH_ENTER(ctx);
+    if (!text2bit || !wildbits) return rh_fail(ctx, REAL_HIP_E_INVALID, "null text", hipSuccess);
+    ctx->have_text = false; ctx->have_index = false;
+    int rc = set_frag(ctx, fileid, n, frag_start, n_frag);
+    if (rc) return rc;
+    if ((rc = alloc_text(ctx, n))) return rc;
+    RH_HIP(ctx, hipMemcpyAsync(ctx->text.p, text2bit, (size_t)((2 * n + 63) / 64) * 8, hipMemcpyHostToDevice, ctx->stream));
+    RH_HIP(ctx, hipMemcpyAsync(ctx->wild.p, wildbits, (size_t)((n + 63) / 64) * 8, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = rh_count_wild(ctx, n))) return rc;
+    ctx->have_text = true;
+    return REAL_HIP_OK;
+}
+
+extern "C" int real_hip_set_text_symbols(real_hip_ctx *ctx, uint32_t fileid, const uint8_t *sym, uint64_t n, int on_device,
+                                         const uint64_t *frag_start, uint32_t n_frag)
+{
+    RH_ENTER(ctx);
+    if (!sym && n) return rh_fail(ctx, REAL_HIP_E_INVALID, "null symbols", hipSuccess);
+    ctx->have_text = false; ctx->have_index = false;
+    int rc = set_frag(ctx, fileid, n, frag_start, n_frag);
+    if (rc) return rc;
+    if ((rc = alloc_text(ctx, n))) return rc;
+    const uint8_t *d_sym = sym;
+    DevBuf tmp;
+    if (!on_device) {
+        if ((rc = rh_reserve(ctx, tmp, n ? n : 1))) return rc;
+        RH_HIP(ctx, hipMemcpyAsync(tmp.p, sym, n, hipMemcpyHostToDevice, ctx->stream));
+        d_sym = (const uint8_t *)tmp.p;
+    }
+    rc = rh_pack_text(ctx, d_sym, n);
+    rh_release(tmp);
+    if (rc) return rc;
+    ctx->have_text = true;
+    return REAL_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// index
+// ---------------------------------------------------------------------------
+extern "C" int real_hip_set_index_block(real_hip_ctx *ctx, uint64_t n, const void *const sign[6], const uint32_t *const pos[6])
+{
+    RH_ENTER(ctx);
+    if (!ctx->have_text) return rh_fail(ctx, REAL_HIP_E_STATE, "set the text first", hipSuccess);
+    if (!sign || !pos || n > 0xffffffffull) return rh_fail(ctx, REAL_HIP_E_INVALID, "bad index block", hipSuccess);
+    const unsigned sb = ctx->prm.seedl <= 32 ? 4 : 8; // real.cpp:219-229
+    ctx->have_index = false;
+    ctx->n_entries = n;
+    ctx->pb = rh_choose_prefix_bits(ctx, n);
+    RhTimer tm(ctx, REAL_HIP_K_INDEX);
+    int rc;
+    if ((rc = rh_reserve(ctx, ctx->keys_a, (n ? n : 1) * sb))) return rc;
+    if ((rc = rh_reserve(ctx, ctx->vals_a, (n ? n : 1) * 4))) return rc;
+    for (int k = 0; k < 6; ++k) {
+        if (n && (!sign[k] || !pos[k])) return rh_fail(ctx, REAL_HIP_E_INVALID, "null list", hipSuccess);
+        if (n) {
+            RH_HIP(ctx, hipMemcpyAsync(ctx->keys_a.p, sign[k], n * sb, hipMemcpyHostToDevice, ctx->stream));
+            RH_HIP(ctx, hipMemcpyAsync(ctx->vals_a.p, pos[k], n * 4, hipMemcpyHostToDevice, ctx->stream));
+        }
+        if ((rc = rh_index_from_sorted(ctx, k, ctx->keys_a.p, (const uint32_t *)ctx->vals_a.p, n, sb))) return rc;
+        RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    rh_release(ctx->keys_a); rh_release(ctx->vals_a);
+    ctx->have_index = true;
+    return REAL_HIP_OK;
+}
+
+extern "C" int real_hip_build_index_block(real_hip_ctx *ctx, uint64_t first_window, uint64_t max_entries,
+                                          uint64_t *n_entries, int *have_next)
+{
+    RH_ENTER(ctx);
+    if (!ctx->have_text) return rh_fail(ctx, REAL_HIP_E_STATE, "set the text first", hipSuccess);
+    ctx->have_index = false;
+    return rh_index_build_device(ctx, first_window, max_entries, n_entries, have_next);
+}
+
+extern "C" int real_hip_index_info(const real_hip_ctx *ctx, uint64_t *n_entries, uint32_t *prefix_bits)
+{
+    if (!ctx || !ctx->have_index) return REAL_HIP_E_STATE;
+    if (n_entries) *n_entries = ctx->n_entries;
+    if (prefix_bits) *prefix_bits = ctx->pb;
+    return REAL_HIP_OK;
+}
+
+extern "C" int real_hip_index_download(real_hip_ctx *ctx, int list, uint32_t *fp, uint32_t *pos, uint32_t *bucket)
+{
+    RH_ENTER(ctx);
+    if (!ctx->have_index) return rh_fail(ctx, REAL_HIP_E_STATE, "no index", hipSuccess);
+    if (list < 0 || list > 5) return rh_fail(ctx, REAL_HIP_E_INVALID, "list", hipSuccess);
+    const uint64_t n = ctx->n_entries;
+    if (n && (fp || pos)) {
+        std::vector<uint2> h;
+        try { h.resize(n); } catch (...) { return rh_fail(ctx, REAL_HIP_E_NOMEM, "host staging", hipSuccess); }
+        RH_HIP(ctx, hipMemcpy(h.data(), ctx->ent[list].p, n * sizeof(uint2), hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < n; ++i) { if (fp) fp[i] = h[i].x; if (pos) pos[i] = h[i].y; }
+    }
+    if (bucket) RH_HIP(ctx, hipMemcpy(bucket, ctx->bkt[list].p, (((size_t)1 << ctx->pb) + 1) * 4, hipMemcpyDeviceToHost));
+    return REAL_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// batches
+// ---------------------------------------------------------------------------
+struct Staged {
+    const uint8_t *bases = nullptr, *qual = nullptr;
+    const uint64_t *off = nullptr;
+    uint32_t upatl = 0, maxpatl = 0, W = 0, QS = 0;
+};
+
+static int stage_batch(real_hip_ctx *ctx, const real_hip_batch *b, Staged &s)
+{
+    if (!b || b->struct_size != sizeof(real_hip_batch)) return rh_fail(ctx, REAL_HIP_E_INVALID, "batch struct_size", hipSuccess);
+    if (!ctx->have_text || !ctx->have_index) return rh_fail(ctx, REAL_HIP_E_STATE, "text and index must be set", hipSuccess);
+    if (b->n_reads > 0xffffffffull) return rh_fail(ctx, REAL_HIP_E_INVALID, "more than 2^32 reads in one batch", hipSuccess);
+    const uint64_t n = b->n_reads;
+    if (!n) return REAL_HIP_OK;
+    if (!b->bases) return rh_fail(ctx, REAL_HIP_E_INVALID, "null bases", hipSuccess);
+    int rc;
+    uint64_t total = 0;
+    if (b->offsets) {
+        if (b->on_device) {
+            s.off = b->offsets;
+            s.maxpatl = b->max_patl;
+            if (!s.maxpatl && (rc = rh_max_patl(ctx, s.off, n, &s.maxpatl))) return rc;
+        } else {
+            for (uint64_t i = 0; i < n; ++i) {
+                if (b->offsets[i + 1] < b->offsets[i]) return rh_fail(ctx, REAL_HIP_E_INVALID, "offsets not monotone", hipSuccess);
+                uint64_t len = b->offsets[i + 1] - b->offsets[i];
+                if (len > s.maxpatl) s.maxpatl = (uint32_t)(len > 0xffffffffull ? 0xffffffffull : len);
+            }
+            total = b->offsets[n];
+            if ((rc = rh_reserve(ctx, ctx->s_off, (n + 1) * 8))) return rc;
+            RH_HIP(ctx, hipMemcpyAsync(ctx->s_off.p, b->offsets, (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+            s.off = (const uint64_t *)ctx->s_off.p;
+        }
+    } else {
+        s.upatl = b->patl; s.maxpatl = b->patl;
+        total = n * (uint64_t)b->patl;
+    }
+    if (b->on_device) {
+        s.bases = b->bases; s.qual = b->qual;
+    } else {
+        if ((rc = rh_reserve(ctx, ctx->s_bases, total ? total : 1))) return rc;
+        RH_HIP(ctx, hipMemcpyAsync(ctx->s_bases.p, b->bases, total, hipMemcpyHostToDevice, ctx->stream));
+        s.bases = (const uint8_t *)ctx->s_bases.p;
+        if (b->qual) {
+            if ((rc = rh_reserve(ctx, ctx->s_qual, total ? total : 1))) return rc;
+            RH_HIP(ctx, hipMemcpyAsync(ctx->s_qual.p, b->qual, total, hipMemcpyHostToDevice, ctx->stream));
+            s.qual = (const uint8_t *)ctx->s_qual.p;
+        }
+    }
+    // Reads longer than the register budget cannot be matched; the reference has no such
+    // limit (RestWordBuffer grows), so this is an explicit, loud error and not a skip.
+    if (s.maxpatl > REAL_HIP_MAX_PATL) return rh_fail(ctx, REAL_HIP_E_UNSUPPORTED, "read longer than REAL_HIP_MAX_PATL", hipSuccess);
+    s.W = (s.maxpatl + 31) / 32;
+    if (s.W < 1) s.W = 1;
+    s.QS = 32 * s.W;
+    if ((rc = rh_reserve(ctx, ctx->words, n * 2 * s.W * 8))) return rc;
+    if ((rc = rh_reserve(ctx, ctx->seeds, n * 4 * 8))) return rc;
+    if ((rc = rh_reserve(ctx, ctx->patl, n * 4))) return rc;
+    if (ctx->prm.scores && (rc = rh_reserve(ctx, ctx->qrows, n * 2 * (size_t)s.QS))) return rc;
+    return rh_launch_pack(ctx, s.bases, s.qual, s.off, s.upatl, n, s.W, s.QS);
+}
+
+static void fill_args(real_hip_ctx *ctx, const Staged &s, uint64_t n, MatchArgs &a)
+{
+    memset(&a, 0, sizeof a);
+    a.t.text = (const uint64_t *)ctx->text.p; a.t.wild = (const uint64_t *)ctx->wild.p;
+    a.t.frag_start = (const uint64_t *)ctx->frag.p; a.t.n = ctx->n_bases; a.t.n_frag = ctx->n_frag;
+    a.t.has_wild = ctx->n_wild ? 1 : 0; a.t.fileid = ctx->fileid;
+    const uint32_t l = ctx->prm.seedl, pb = ctx->pb;
+    for (int k = 0; k < 6; ++k) { a.ix.ent[k] = (const uint2 *)ctx->ent[k].p; a.ix.bkt[k] = (const uint32_t *)ctx->bkt[k].p; }
+    a.ix.n = ctx->n_entries; a.ix.pb = pb; a.ix.pshift = l - pb; a.ix.fshift = (l > pb + 32) ? (l - pb - 32) : 0;
+    a.b.words = (const uint64_t *)ctx->words.p; a.b.seeds = (const uint64_t *)ctx->seeds.p;
+    a.b.qrows = (const uint8_t *)ctx->qrows.p; a.b.patl = (const uint32_t *)ctx->patl.p;
+    a.b.n_reads = n; a.b.W = s.W; a.b.QS = s.QS;
+    a.LL = (const double *)ctx->LL.p;
+    a.counters = (unsigned long long *)ctx->counters.p;
+    a.filter_mult = ctx->prm.filter_mult;
+    a.l = l; a.q = l / 4; a.b_bits = 2 * (l / 4); a.seedkmax = ctx->prm.seedkmax; a.totalkmax = ctx->prm.totalkmax;
+}
+
+extern "C" int real_hip_match_unique(real_hip_ctx *ctx, const real_hip_batch *b, uint64_t *info, float *score)
+{
+    RH_ENTER(ctx);
+    Staged s;
+    int rc = stage_batch(ctx, b, s);
+    if (rc) return rc;
+    const uint64_t n = b->n_reads;
+    if (!n) return REAL_HIP_OK;
+    const bool sc = ctx->prm.scores != 0;
+    if (!info || (sc && !score)) return rh_fail(ctx, REAL_HIP_E_INVALID, "null info/score", hipSuccess);
+    uint64_t *d_info = info;
+    float *d_score = score;
+    if (!b->on_device) {
+        if ((rc = rh_reserve(ctx, ctx->s_info, n * 8))) return rc;
+        RH_HIP(ctx, hipMemcpyAsync(ctx->s_info.p, info, n * 8, hipMemcpyHostToDevice, ctx->stream));
+        d_info = (uint64_t *)ctx->s_info.p;
+        if (sc) {
+            if ((rc = rh_reserve(ctx, ctx->s_score, n * 4))) return rc;
+            RH_HIP(ctx, hipMemcpyAsync(ctx->s_score.p, score, n * 4, hipMemcpyHostToDevice, ctx->stream));
+            d_score = (float *)ctx->s_score.p;
+        }
+    }
+    MatchArgs a;
+    fill_args(ctx, s, n, a);
+    a.info = d_info; a.score = d_score;
+    if ((rc = rh_launch_match(ctx, a, false))) return rc;
+    if (!b->on_device) {
+        RH_HIP(ctx, hipMemcpyAsync(info, d_info, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (sc) RH_HIP(ctx, hipMemcpyAsync(score, d_score, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return REAL_HIP_OK;
+}
+
+extern "C" int real_hip_match_all(real_hip_ctx *ctx, const real_hip_batch *b, real_hip_hit *out, uint64_t cap,
+                                  uint64_t *n_out, uint64_t *hit_offsets)
+{
+    RH_ENTER(ctx);
+    Staged s;
+    int rc = stage_batch(ctx, b, s);
+    if (rc) return rc;
+    const uint64_t n = b->n_reads;
+    if (n_out) *n_out = 0;
+    if (cap > 0xffffffffull) cap = 0xffffffffull; // record indices are 32 bit inside the post-pass
+    if ((rc = rh_reserve(ctx, ctx->raw_count, 8))) return rc;
+    RH_HIP(ctx, hipMemsetAsync(ctx->raw_count.p, 0, 8, ctx->stream));
+    if ((rc = rh_reserve(ctx, ctx->raw, (cap ? cap : 1) * sizeof(uint4)))) return rc;
+    unsigned long long n_raw = 0;
+    if (n) {
+        MatchArgs a;
+        fill_args(ctx, s, n, a);
+        a.raw = (uint4 *)ctx->raw.p; a.raw_count = (unsigned long long *)ctx->raw_count.p; a.raw_cap = cap;
+        if ((rc = rh_launch_match(ctx, a, true))) return rc;
+        RH_HIP(ctx, hipMemcpyAsync(&n_raw, ctx->raw_count.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+        RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (n_out) *n_out = n_raw;
+    if (n_raw > cap) return rh_fail(ctx, REAL_HIP_E_OVERFLOW, "hit buffer too small", hipSuccess);
+    real_hip_hit *d_out = out;
+    uint64_t *d_off = hit_offsets;
+    if (!b->on_device) {
+        if ((rc = rh_reserve(ctx, ctx->s_hits, (n_raw ? n_raw : 1) * sizeof(real_hip_hit)))) return rc;
+        d_out = (real_hip_hit *)ctx->s_hits.p;
+        if (hit_offsets) {
+            if ((rc = rh_reserve(ctx, ctx->hit_off, (n + 1) * 8))) return rc;
+            d_off = (uint64_t *)ctx->hit_off.p;
+        }
+    }
+    if ((n_raw && !out) ) return rh_fail(ctx, REAL_HIP_E_INVALID, "null hit buffer", hipSuccess);
+    if ((rc = rh_all_finish(ctx, n_raw, n, d_out, d_off))) return rc;
+    if (!b->on_device) {
+        if (n_raw) RH_HIP(ctx, hipMemcpyAsync(out, d_out, n_raw * sizeof(real_hip_hit), hipMemcpyDeviceToHost, ctx->stream));
+        if (hit_offsets) RH_HIP(ctx, hipMemcpyAsync(hit_offsets, d_off, (n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return REAL_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// counters / timing
+// ---------------------------------------------------------------------------
+extern "C" int real_hip_counters_get(real_hip_ctx *ctx, real_hip_counters *out, int reset)
+{
+    RH_ENTER(ctx);
+    uint64_t h[8];
+    RH_HIP(ctx, hipMemcpyAsync(h, ctx->counters.p, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    if (reset) RH_HIP(ctx, hipMemsetAsync(ctx->counters.p, 0, sizeof h, ctx->stream));
+    RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (out) {
+        out->reads = h[0]; out->lookups = h[1]; out->probes = h[2]; out->candidates = h[3];
+        out->seedpass = h[4]; out->hits = h[5]; out->verified = h[6]; out->reserved = 0;
+    }
+    return REAL_HIP_OK;
+}
+
+extern "C" int real_hip_kernel_time(real_hip_ctx *ctx, int which, double *total_ms, uint64_t *launches, int reset)
+{
+    if (!ctx || which < 0 || which >= REAL_HIP_K_COUNT) return REAL_HIP_E_INVALID;
+    if (total_ms) *total_ms = ctx->k_ms[which];
+    if (launches) *launches = ctx->k_n[which];
+    if (reset) { ctx->k_ms[which] = 0; ctx->k_n[which] = 0; }
+    return REAL_HIP_OK;
+}
+
+extern "C" int real_hip_timing_enable(real_hip_ctx *ctx, int on)
+{
+    if (!ctx) return REAL_HIP_E_INVALID;
+    ctx->timing = on != 0;
+    return REAL_HIP_OK;
+}

@@ -1,0 +1,137 @@
+// real_hip_internal.h -- shared between the translation units of libreal_hip.so.
+// gfx950 only; no portability layers.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "real_hip.h"
+
+#define RH_MAXW 8 /* 64-bit words per oriented read: REAL_HIP_MAX_PATL / 32 */
+
+// ---- device-side views ------------------------------------------------------
+struct DevText {
+    const uint64_t *text;       // 2-bit text, MSB first, padded by 4 zero words
+    const uint64_t *wild;       // N bit vector, MSB first, padded
+    const uint64_t *frag_start; // n_frag + 1
+    uint64_t n;                 // bases
+    uint32_t n_frag;
+    uint32_t has_wild;
+    uint32_t fileid;
+};
+
+// One entry of a sorted list: {fingerprint, window start}.  The fingerprint is
+// 32 bits of the signature just below the bucket prefix; entries of a bucket
+// are in the reference's list order (signature ascending, stable => position
+// ascending), so equal fingerprints are contiguous and the members of the
+// reference's equal range appear in the reference's order.
+struct DevIndex {
+    const uint2    *ent[6];
+    const uint32_t *bkt[6]; // 2^pb + 1 bucket starts
+    uint64_t n;
+    uint32_t pb;     // prefix bits
+    uint32_t pshift; // sig_bits - pb
+    uint32_t fshift; // max(sig_bits - pb - 32, 0)
+};
+
+struct DevBatch {
+    const uint64_t *words; // [n_reads][2][W]   oriented reads, 32 bases / word, MSB first
+    const uint64_t *seeds; // [n_reads][2][2]   seed halves (s0, s5) of each orientation
+    const uint8_t  *qrows; // [n_reads][2][QS]  oriented quality rows (16-byte aligned)
+    const uint32_t *patl;  // [n_reads]         0 = skipped read
+    uint64_t n_reads;
+    uint32_t W, QS;
+};
+
+struct MatchArgs {
+    DevText  t;
+    DevIndex ix;
+    DevBatch b;
+    const double *LL;      // device copy of the 4x4x64 table
+    uint64_t *info;        // in/out records
+    float    *score;       // in/out scores (scores mode)
+    unsigned long long *counters; // 8 x u64
+    // matchAll
+    uint4 *raw;            // raw hit records
+    unsigned long long *raw_count;
+    uint64_t raw_cap;
+    double   filter_mult;
+    uint32_t l, q, b_bits, seedkmax, totalkmax;
+};
+
+// ---- host context ------------------------------------------------------------
+struct DevBuf {
+    void  *p = nullptr;
+    size_t cap = 0;
+};
+
+struct real_hip_ctx {
+    real_hip_params prm;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+
+    // text
+    DevBuf text, wild, frag;
+    uint64_t n_bases = 0;
+    uint64_t n_wild = 0;
+    uint32_t n_frag = 0, fileid = 0;
+    bool have_text = false;
+
+    // index
+    DevBuf ent[6], bkt[6];
+    uint64_t n_entries = 0;
+    uint32_t pb = 0;
+    bool have_index = false;
+
+    // tables / counters
+    DevBuf LL, counters;
+
+    // batch staging + packed form
+    DevBuf s_bases, s_qual, s_off, s_info, s_score;
+    DevBuf words, seeds, qrows, patl, maxpatl;
+    // matchAll workspace
+    DevBuf raw, raw_count, keys_a, keys_b, vals_a, vals_b, sort_tmp, hit_off, s_hits;
+
+    // timing
+    bool timing = true;
+    double   k_ms[REAL_HIP_K_COUNT] = {0, 0, 0, 0, 0};
+    uint64_t k_n[REAL_HIP_K_COUNT] = {0, 0, 0, 0, 0};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+// error plumbing: never throw across the ABI
+int rh_fail(real_hip_ctx *ctx, int status, const char *what, hipError_t e);
+#define RH_HIP(ctx, call)                                                          \
+    do {                                                                           \
+        hipError_t _e = (call);                                                    \
+        if (_e != hipSuccess) return rh_fail((ctx), REAL_HIP_E_DEVICE, #call, _e); \
+    } while (0)
+int rh_reserve(real_hip_ctx *ctx, DevBuf &b, size_t bytes);
+void rh_release(DevBuf &b);
+
+struct RhTimer { // HIP events on the ctx stream around a group of launches
+    real_hip_ctx *c;
+    int which;
+    RhTimer(real_hip_ctx *ctx, int w);
+    ~RhTimer();
+};
+
+// ---- kernels launchers (match_kernels.hip) -----------------------------------
+int rh_launch_pack(real_hip_ctx *ctx, const uint8_t *d_bases, const uint8_t *d_qual,
+                   const uint64_t *d_off, uint32_t uniform_patl, uint64_t n_reads,
+                   uint32_t W, uint32_t QS);
+int rh_launch_match(real_hip_ctx *ctx, const MatchArgs &a, bool all);
+int rh_max_patl(real_hip_ctx *ctx, const uint64_t *d_off, uint64_t n_reads, uint32_t *out);
+int rh_all_finish(real_hip_ctx *ctx, uint64_t n_raw, uint64_t n_reads, real_hip_hit *d_out,
+                  uint64_t *d_hit_offsets);
+
+// ---- text + index (index_build.hip) ------------------------------------------
+int rh_pack_text(real_hip_ctx *ctx, const uint8_t *d_sym, uint64_t n);
+int rh_index_from_sorted(real_hip_ctx *ctx, int list, const void *d_sign, const uint32_t *d_pos,
+                         uint64_t n, unsigned sig_bytes);
+int rh_index_build_device(real_hip_ctx *ctx, uint64_t first_window, uint64_t max_entries,
+                          uint64_t *n_entries, int *have_next);
+uint32_t rh_choose_prefix_bits(const real_hip_ctx *ctx, uint64_t n_entries);

@@ -1,0 +1,190 @@
+"""Parity tests proper: the HIP path, called through the C ABI (libreal_hip.so),
+against the oracle on the same seeded inputs.  Bit-exact: records (state,
+fragment, errors, file, position), float score bits, matchAll hit lists, and
+the logical work counters.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from real_amd import host_index, synth
+from real_amd.matcher import AllMatcher, RealOptions, UniqueMatcher, new_unique_info, unpack_info
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+def _opts(seedl, seedkmax, totalkmax, scores, filter_level=2):
+    return RealOptions(seedl=seedl, seedkmax=seedkmax, totalkmax=totalkmax, scores=bool(scores),
+                       filter_level=filter_level).normalise()
+
+
+def _oracle_unique(ora, g, sym, frag, seedl, n_list, p, bases, qual, offsets):
+    og = ora.Genome(sym, frag)
+    info = np.zeros(offsets.shape[0] - 1, dtype=np.uint64)
+    score = np.full(offsets.shape[0] - 1, ora.NOSCORE_INIT, dtype=np.float32)
+    first = 0
+    tot = None
+    while True:
+        ix = ora.Index(og, seedl, first_window=first, max_entries=(n_list if n_list else 1 << 62))
+        info, score, ctr = ora.match_unique(og, ix, p, bases, qual, offsets, info=info, score=score)
+        tot = ctr if tot is None else {k: tot[k] + ctr[k] for k in tot}
+        first += ix.n
+        if not ix.have_next:
+            break
+    return info, score, tot
+
+
+def _compare_unique(info, score, oinfo, oscore, scores):
+    st, fr, er, fi, po = unpack_info(info)
+    ost, ofr, oer, ofi, opo = unpack_info(oinfo)
+    assert np.array_equal(st, ost), "match state differs"
+    assert np.array_equal(er, oer), "mismatch count differs"
+    # raw records are bit-identical too (the pos/frag bits of a NonUnique record are those of
+    # the first hit seen at that level in canonical order, which the device fold preserves)
+    assert np.array_equal(info, oinfo), "records differ"
+    if scores:
+        assert np.array_equal(np.asarray(score).view(np.uint32), np.asarray(oscore).view(np.uint32)), "score bits differ"
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+@pytest.mark.parametrize("builder", ["device", "host"])
+def test_match_unique_golden_inputs(ora, path, builder):
+    z = np.load(path)
+    seedl, seedkmax, totalkmax, scores, n_list = [int(x) for x in z["params"]]
+    sym, frag = z["genome"], z["frag_start"]
+    bases, qual, offsets = z["bases"], z["qual"], z["offsets"]
+    opts = _opts(seedl, seedkmax, totalkmax, scores)
+    p = ora.make_params(seedl=seedl, seedkmax=seedkmax, totalkmax=totalkmax, scores=scores)
+    oinfo, oscore, octr = _oracle_unique(ora, None, sym, frag, seedl, n_list, p, bases, qual, offsets)
+
+    m = UniqueMatcher(opts)
+    assert np.array_equal(m.LL.view(np.uint64), np.array(list(p.LL)).view(np.uint64)), "LL table differs from the oracle's"
+    if builder == "device":
+        m.set_text_symbols(0, sym, frag)
+    else:
+        text, wild = host_index.pack_text(sym)
+        m.set_text(0, text, wild, sym.shape[0], frag)
+    info, score = new_unique_info(offsets.shape[0] - 1, scores)
+    first = 0
+    m.counters(reset=True)
+    while True:
+        if builder == "device":
+            n, nxt = m.build_index_block(first, n_list if n_list else 1 << 62)
+        else:
+            sign, pos, n, nxt = host_index.build_lists(sym, seedl, first, n_list if n_list else 1 << 62)
+            m.set_index_block(sign, pos)
+        m.match_unique(bases, qual, offsets, info=info, score=score)
+        first += n
+        if not nxt:
+            break
+    _compare_unique(info, score, oinfo, oscore, scores)
+    c = m.counters()
+    for k in ("reads", "lookups", "candidates", "seedpass", "hits"):
+        assert c[k] == octr[k], "work counter %s: %d != oracle %d" % (k, c[k], octr[k])
+    m.close()
+
+
+def _hits_tuple(h):
+    return (h["read"].astype(np.int64), h["pos"].astype(np.int64), h["frag"].astype(np.int64),
+            h["k"].astype(np.int64), h["inverted"].astype(np.int64), h["score"].view(np.uint32).astype(np.int64))
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_match_all_golden_inputs(ora, path):
+    z = np.load(path)
+    seedl, seedkmax, totalkmax, scores, n_list = [int(x) for x in z["params"]]
+    if n_list:
+        pytest.skip("matchAll is per block; covered by the one-block cases")
+    sym, frag = z["genome"], z["frag_start"]
+    bases, qual, offsets = z["bases"], z["qual"], z["offsets"]
+    p = ora.make_params(seedl=seedl, seedkmax=seedkmax, totalkmax=totalkmax, scores=scores)
+    og = ora.Genome(sym, frag)
+    ix = ora.Index(og, seedl)
+    ohits, ooff, octr = ora.match_all(og, ix, p, bases, qual, offsets)
+    m = AllMatcher(_opts(seedl, seedkmax, totalkmax, scores))
+    m.set_text_symbols(0, sym, frag)
+    m.build_index_block()
+    hits, hoff = m.match_all(bases, qual, offsets, cap=8)      # tiny cap: exercises the overflow retry
+    m.counters(reset=True)
+    hits2, hoff2 = m.match_all(bases, qual, offsets)
+    assert np.array_equal(hits, hits2) and np.array_equal(hoff, hoff2)
+    assert np.array_equal(hoff, ooff), "per-read hit counts differ"
+    for a, b in zip(_hits_tuple(hits), _hits_tuple(ohits)):
+        assert np.array_equal(a, b)
+    c = m.counters()
+    for k in ("reads", "lookups", "candidates", "seedpass", "hits"):
+        assert c[k] == octr[k], "work counter %s: %d != oracle %d" % (k, c[k], octr[k])
+    m.close()
+
+
+@pytest.mark.parametrize("seedl,patl,k,scores,pb", [
+    (32, 100, 3, 1, 0), (32, 100, 3, 0, 0), (32, 36, 0, 0, 0), (64, 150, 5, 1, 0),
+    (32, 100, 3, 1, 4),          # 16 buckets: every bucket is large -> in-bucket binary search path
+    (64, 150, 5, 1, 12),         # signature wider than prefix+32: fingerprint + text confirmation path
+    (16, 50, 4, 1, 0), (20, 255, 15, 1, 0), (4, 20, 2, 0, 0), (32, 32, 2, 1, 0),
+])
+def test_match_unique_random(ora, seedl, patl, k, scores, pb):
+    g = synth.random_genome(200_000 if seedl >= 16 else 3000, seed=100 + seedl + patl, n_frag=5, n_runs=20, repeats=30)
+    b = synth.sample_reads(g, 4000 if seedl >= 16 else 300, patl, 0.02, seed=200 + patl, n_read_prob=0.0005)
+    seedk = min(2, k)
+    p = ora.make_params(seedl=seedl, seedkmax=seedk, totalkmax=k, scores=scores)
+    oinfo, oscore, octr = _oracle_unique(ora, None, g.sym, g.frag_start, seedl, 0, p, b.bases, b.qual, b.offsets)
+    m = UniqueMatcher(_opts(seedl, seedk, k, scores), prefix_bits=pb)
+    m.set_text_symbols(0, g.sym, g.frag_start)
+    m.build_index_block()
+    info, score = m.match_unique(b.bases, b.qual, patl=patl)        # uniform-length batch form
+    _compare_unique(info, score, oinfo, oscore, scores)
+    c = m.counters()
+    for kk in ("reads", "lookups", "candidates", "seedpass", "hits"):
+        assert c[kk] == octr[kk], (kk, c[kk], octr[kk])
+    m.close()
+
+
+def test_index_layout_device_equals_host(ora):
+    g = synth.random_genome(50_000, seed=77, n_frag=3, n_runs=10, repeats=10)
+    for seedl in (32, 64, 12):
+        a = UniqueMatcher(_opts(seedl, 2, 3, 1))
+        a.set_text_symbols(0, g.sym, g.frag_start)
+        a.build_index_block()
+        h = UniqueMatcher(_opts(seedl, 2, 3, 1))
+        text, wild = host_index.pack_text(g.sym)
+        h.set_text(0, text, wild, g.n, g.frag_start)
+        sign, pos, n, nxt = host_index.build_lists(g.sym, seedl)
+        h.set_index_block(sign, pos)
+        assert a.n_entries == h.n_entries == n and a.prefix_bits == h.prefix_bits
+        og = ora.Genome(g.sym, g.frag_start)
+        oix = ora.Index(og, seedl)
+        for k in range(6):
+            fa, pa, ba = a.index_download(k)
+            fh, ph, bh = h.index_download(k)
+            assert np.array_equal(fa, fh) and np.array_equal(pa, ph) and np.array_equal(ba, bh)
+            assert np.array_equal(pa, oix.pos(k)), "device list order != reference list order"
+            # bucket table: starts are the lower bounds of the prefixes
+            pref = (oix.sign(k) >> np.uint64(seedl - a.prefix_bits)).astype(np.int64)
+            want = np.searchsorted(pref, np.arange((1 << a.prefix_bits) + 1), side="left")
+            assert np.array_equal(ba.astype(np.int64), want)
+        a.close(); h.close()
+
+
+def test_errors_are_loud():
+    from real_amd.lib import RealHipError
+    m = UniqueMatcher(_opts(32, 2, 3, 1))
+    with pytest.raises(RealHipError):           # no text yet
+        m.build_index_block()
+    g = synth.random_genome(5000, seed=5)
+    m.set_text_symbols(0, g.sym, g.frag_start)
+    with pytest.raises(RealHipError):           # no index yet
+        m.match_unique(np.zeros(100, np.uint8), np.zeros(100, np.uint8), patl=100)
+    m.build_index_block()
+    with pytest.raises(RealHipError):           # longer than REAL_HIP_MAX_PATL: an error, not a silent skip
+        m.match_unique(np.zeros(300, np.uint8), np.zeros(300, np.uint8), patl=300)
+    # empty batch and all-skipped batch are fine
+    info, score = m.match_unique(np.zeros(0, np.uint8), np.zeros(0, np.uint8), patl=100, n_reads=0)
+    assert info.shape[0] == 0
+    info, score = m.match_unique(np.full(40, 4, np.uint8), np.zeros(40, np.uint8), patl=20)
+    assert np.all(info == 0)
+    m.close()
