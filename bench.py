@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""bench.py -- REAL read-matching hot path on MI355X.
+
+One step = one pass of the hot path (pack -> signatures -> bucket lookup -> seed
+filter -> verify -> score -> best/unique fold) over one batch of synthetic reads
+that is already resident in HBM.  Workload = BASELINE.json configs[1]:
+matchUnique, 50M synthetic 100 bp FASTQ reads vs a 3 Gbp synthetic genome,
+k=3 (seed k<=2), scores on.  With --gpus N every rank holds the whole index
+(replicated) and its own shard of reads (weak scaling, C4 = 8 x 50M); the only
+data-path communication is one RCCL gather of the per-read records to rank 0.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes(c, patl, seedl, scores):
+    """A = R*B_io + L*8 + P*w + C*(8+w) + S*(3*18+8+8*W_rest) + H*(18+8*W_score),
+    evaluated with the kernel's own work counters (P = index entries examined)."""
+    w = 4 if seedl <= 32 else 8
+    w_rest = -(-(patl - seedl) // 32) + 1
+    w_score = (-(-patl // 32) + 1) if scores else 0
+    b_io = -(-patl // 4) + (patl if scores else 0) + 2 * (8 + (4 if scores else 0))
+    return (c["reads"] * b_io + c["lookups"] * 8 + c["probes"] * w + c["candidates"] * (8 + w) +
+            c["seedpass"] * (3 * 18 + 8 + 8 * w_rest) + c["hits"] * (18 + 8 * w_score))
+
+
+def _synth():
+    import ctypes as C
+    L = C.CDLL(os.path.join(ROOT, "real_amd", "libreal_synth.so"))
+    L.real_synth_genome.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+    L.real_synth_positions.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]
+    L.real_synth_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_double, C.c_uint64,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]
+    return L
+
+
+def gen_genome(torch, G, seed, device):
+    """randstr.cpp:27-53: i.i.d. uniform ACGT, generated on the device (bench_support/synth_kernels.hip)."""
+    sym = torch.empty(G, dtype=torch.uint8, device=device)
+    torch.cuda.synchronize()
+    rc = _synth().real_synth_genome(sym.data_ptr(), G, seed)
+    assert rc == 0, "synth_genome failed: hip error %d" % rc
+    return sym
+
+
+def gen_reads(torch, sym, n_reads, patl, errprob, seed, device):
+    """genpat's distribution (genpat.cpp:96-157) on the device: sorted uniform start
+    positions, strand flip p=0.5, per-base substitution to a different base with
+    probability errprob, quality 35 ('D'-33) unchanged / 9 ('*'-33) mutated."""
+    L = _synth()
+    n = sym.shape[0]
+    pos = torch.empty(n_reads, dtype=torch.int64, device=device)
+    torch.cuda.synchronize()
+    rc = L.real_synth_positions(pos.data_ptr(), n_reads, n - patl + 1, seed)
+    assert rc == 0
+    pos, _ = torch.sort(pos)          # genpat sorts the sampled positions (genpat.cpp:99)
+    bases = torch.empty(n_reads * patl, dtype=torch.uint8, device=device)
+    qual = torch.empty(n_reads * patl, dtype=torch.uint8, device=device)
+    torch.cuda.synchronize()
+    rc = L.real_synth_reads(sym.data_ptr(), pos.data_ptr(), n_reads, patl, errprob, seed, bases.data_ptr(), qual.data_ptr(), None)
+    assert rc == 0, "synth_reads failed: hip error %d" % rc
+    return bases, qual, pos
+
+
+def cpu_baseline(torch, m, sym_host, frag, opts, bases, qual, patl, n_reads, threads, target_s=15.0):
+    """The oracle (a port of the reference's OpenMP/popcnt path) timed on this box's host
+    cores on a bounded sample of the SAME workload: same genome, same index (the six sorted
+    lists downloaded from the GPU), a strided sample of the same reads."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ora
+    t0 = time.time()
+    og = ora.Genome(sym_host, frag)
+    ents = []
+    for k in range(6):
+        e, _ = m.index_download(k, want_buckets=False)
+        ents.append(e)
+    ix = ora.CompactIndex(og, opts.seedl, ents)
+    p = ora.make_params(seedl=opts.seedl, seedkmax=opts.seedkmax, totalkmax=opts.totalkmax, scores=opts.scores,
+                        filter_level=opts.filter_level, threads=threads)
+    setup_s = time.time() - t0
+
+    def sample(k):
+        stride = max(1, n_reads // k)           # strided slice: no gather kernels on >2^31-element tensors
+        b = bases.view(n_reads, patl)[::stride][:k].contiguous().cpu().numpy().reshape(-1)
+        q = qual.view(n_reads, patl)[::stride][:k].contiguous().cpu().numpy().reshape(-1)
+        k = b.shape[0] // patl
+        off = (np.arange(k + 1, dtype=np.uint64) * np.uint64(patl))
+        return b, q, off, (stride, k)
+
+    k0 = min(n_reads, 50_000)
+    b, q, off, _ = sample(k0)
+    t = time.time(); ora.match_unique(og, ix, p, b, q, off); pilot = time.time() - t
+    k1 = int(min(n_reads, max(k0, k0 * target_s / max(pilot, 1e-3))))
+    b, q, off, idx = sample(k1)
+    k1 = idx[1]
+    t = time.time(); oinfo, oscore, octr = ora.match_unique(og, ix, p, b, q, off); dt = time.time() - t
+    return {"value": k1 / dt, "unit": "reads/s", "cores": threads, "kind": "port",
+            "sample": "%d of the step's %d reads (strided), same %.0f Mbp genome and index (six sorted lists downloaded "
+                      "from the GPU), oracle/real_oracle.c with OpenMP, %.1f s of CPU work (+%.0f s index transfer/setup)"
+                      % (k1, n_reads, og.n / 1e6, dt, setup_s)}, (idx, oinfo, oscore)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genome-mbp", type=float, default=3000.0, help="synthetic genome size (BASELINE: 3000)")
+    ap.add_argument("--reads", type=int, default=50_000_000, help="reads per GPU per step (BASELINE: 50M)")
+    ap.add_argument("--patl", type=int, default=100)
+    ap.add_argument("--seedl", type=int, default=32)
+    ap.add_argument("--totalk", type=int, default=3)
+    ap.add_argument("--scores", type=int, default=1)
+    ap.add_argument("--prefix-bits", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from real_amd import lib as rlib
+    from real_amd.matcher import RealOptions, UniqueMatcher
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")     # RCCL over xGMI
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    G = int(args.genome_mbp * 1e6)
+    opts = RealOptions(seedl=args.seedl, seedkmax=2, totalkmax=args.totalk, scores=bool(args.scores), filter_level=2).normalise()
+    def log(msg):
+        if rank == 0:
+            print("[bench %7.1fs] %s" % (time.time() - t_start, msg), file=sys.stderr, flush=True)
+    t_start = time.time()
+    t_setup = time.time()
+    sym = gen_genome(torch, G, 3, dev)                       # i.i.d. uniform ACGT, one fragment, seed 3
+    frag = np.array([0, G], dtype=np.uint64)
+    m = UniqueMatcher(opts, device=local, prefix_bits=args.prefix_bits)
+    torch.cuda.synchronize()
+    log("genome generated")
+    m.set_text_symbols(0, sym, frag)
+    log("text packed")
+    t0 = time.time()
+    n_entries, _ = m.build_index_block()
+    t_index = time.time() - t0
+    log("index built: %d entries, prefix_bits %d, %.1f s" % (n_entries, m.prefix_bits, t_index))
+    n = args.reads
+    bases, qual, true_pos = gen_reads(torch, sym, n, args.patl, 0.02, 4 + rank, dev)
+    log("reads generated")
+    sym_host = sym.cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    del sym
+    torch.cuda.empty_cache()
+    info = torch.zeros(n, dtype=torch.int64, device=dev)
+    score = torch.empty(n, dtype=torch.float32, device=dev)
+    gather_info = [torch.empty_like(info) for _ in range(world)] if (world > 1 and rank == 0) else None
+    gather_score = [torch.empty_like(score) for _ in range(world)] if (world > 1 and rank == 0) else None
+    t_setup = time.time() - t_setup
+
+    def step():
+        info.zero_(); score.fill_(-3.4028234663852886e38)     # uniqueinfo(numpat): state NoMatch, score -FLT_MAX
+        torch.cuda.current_stream().synchronize()
+        m.match_unique(bases, qual, patl=args.patl, info=info, score=score, n_reads=n)
+        if world > 1:                                          # the one collective: records to the root
+            dist.gather(info, gather_info, dst=0)
+            dist.gather(score, gather_score, dst=0)
+
+    for _ in range(args.warmup):
+        step()
+    log("warmup done")
+    m.counters(reset=True)
+    for k in (rlib.K_PACK, rlib.K_MATCH_UNIQUE):
+        m.kernel_time(k, reset=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    log("timed steps done: %.1f ms/step" % (dt / args.steps * 1e3))
+    ctr = m.counters()
+    match_ms, match_n = m.kernel_time(rlib.K_MATCH_UNIQUE)
+    pack_ms, pack_n = m.kernel_time(rlib.K_PACK)
+
+    if rank == 0:
+        K = args.steps
+        value = world * n * K / dt
+        a_total = algorithmic_bytes(ctr, args.patl, args.seedl, bool(args.scores))
+        a_launch = a_total / max(match_n, 1)
+        avg_ms = match_ms / max(match_n, 1)
+        achieved = a_launch / (avg_ms * 1e-3) / 1e9
+        st = (info.view(torch.int64) >> 61) & 7
+        aligned = int(((st == 1) | (st == 2)).sum().item())
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            try:
+                tj = json.load(open(tfile))
+                key = "match_unique_%dMbp_%dreads" % (int(args.genome_mbp), n)
+                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "aligned reads/sec (100 bp, k≤3) at 1/2/4/8 MI355X; achieved HBM GB/s vs peak",
+            "value": value, "unit": "reads/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "matchUnique, %dM synthetic %d bp FASTQ reads per GPU vs %.0f Mbp synthetic genome, "
+                                   "k=%d (seed k<=2), scores %s, %dxMI355X" % (n // 1_000_000, args.patl, args.genome_mbp,
+                                                                               args.totalk, "on" if args.scores else "off", world),
+                       "genome_bp": G, "reads_per_gpu_per_step": n, "read_len": args.patl, "seedl": args.seedl,
+                       "seedkmax": 2, "totalkmax": args.totalk, "scores": bool(args.scores), "errprob": 0.02,
+                       "index_entries": n_entries, "prefix_bits": m.prefix_bits,
+                       "parallelism": "reads sharded x%d, index replicated, one RCCL gather of records" % world,
+                       "uniquely_aligned_frac_rank0": aligned / n, "index_build_s": t_index, "setup_s": t_setup},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "match_kernel<4,scores,unique>", "avg_launch_ms": avg_ms, "launches": match_n,
+                         "algorithmic_bytes_per_read": a_total / max(ctr["reads"], 1),
+                         "pack_kernel_avg_ms": pack_ms / max(pack_n, 1),
+                         "work_per_read": {k: ctr[k] / max(ctr["reads"], 1) for k in ("lookups", "probes", "candidates", "seedpass", "hits", "verified")}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, (idx, oinfo, oscore) = cpu_baseline(torch, m, sym_host, frag, opts, bases, qual, args.patl, n, args.cpu_threads)
+            # the sample doubles as a full-size parity check: GPU records of the sampled reads == CPU port
+            stride, k1 = idx
+            gi = info[::stride][:k1].contiguous().cpu().numpy().view(np.uint64)
+            gs = score[::stride][:k1].contiguous().cpu().numpy()
+            cb["parity_on_sample"] = bool(np.array_equal(gi, oinfo) and np.array_equal(gs.view(np.uint32), oscore.view(np.uint32)))
+            out["cpu_baseline"] = cb
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

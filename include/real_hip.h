@@ -106,8 +106,9 @@ int real_hip_build_index_block(real_hip_ctx *ctx, uint64_t first_window, uint64_
                                uint64_t *n_entries, int *have_next);
 /* introspection (tests, CPU baseline): device layout of list k               */
 int real_hip_index_info(const real_hip_ctx *ctx, uint64_t *n_entries, uint32_t *prefix_bits);
-int real_hip_index_download(real_hip_ctx *ctx, int list, uint32_t *fingerprint, uint32_t *pos,
-                            uint32_t *bucket_start /* 2^prefix_bits + 1 */);
+int real_hip_index_download(real_hip_ctx *ctx, int list,
+                            uint32_t *entries      /* n_entries x {fingerprint, pos}, nullable */,
+                            uint32_t *bucket_start /* 2^prefix_bits + 1, nullable          */);
 
 /* ---- read batch: a decoded pattern block (PatternBlock / FastSubDecoder::
  * fillPatternBlock, FastSubDecoder.hpp:107-161): mapped symbols A,C,G,T->0..3,

@@ -289,18 +289,13 @@ extern "C" int real_hip_index_info(const real_hip_ctx *ctx, uint64_t *n_entries,
     return REAL_HIP_OK;
 }
 
-extern "C" int real_hip_index_download(real_hip_ctx *ctx, int list, uint32_t *fp, uint32_t *pos, uint32_t *bucket)
+extern "C" int real_hip_index_download(real_hip_ctx *ctx, int list, uint32_t *entries, uint32_t *bucket)
 {
     RH_ENTER(ctx);
     if (!ctx->have_index) return rh_fail(ctx, REAL_HIP_E_STATE, "no index", hipSuccess);
     if (list < 0 || list > 5) return rh_fail(ctx, REAL_HIP_E_INVALID, "list", hipSuccess);
     const uint64_t n = ctx->n_entries;
-    if (n && (fp || pos)) {
-        std::vector<uint2> h;
-        try { h.resize(n); } catch (...) { return rh_fail(ctx, REAL_HIP_E_NOMEM, "host staging", hipSuccess); }
-        RH_HIP(ctx, hipMemcpy(h.data(), ctx->ent[list].p, n * sizeof(uint2), hipMemcpyDeviceToHost));
-        for (uint64_t i = 0; i < n; ++i) { if (fp) fp[i] = h[i].x; if (pos) pos[i] = h[i].y; }
-    }
+    if (n && entries) RH_HIP(ctx, hipMemcpy(entries, ctx->ent[list].p, n * sizeof(uint2), hipMemcpyDeviceToHost));
     if (bucket) RH_HIP(ctx, hipMemcpy(bucket, ctx->bkt[list].p, (((size_t)1 << ctx->pb) + 1) * 4, hipMemcpyDeviceToHost));
     return REAL_HIP_OK;
 }

@@ -96,7 +96,7 @@ def load():
     L.real_hip_set_index_block.argtypes = [vp, u64, C.POINTER(vp), C.POINTER(vp)]
     L.real_hip_build_index_block.argtypes = [vp, u64, u64, C.POINTER(u64), C.POINTER(C.c_int)]
     L.real_hip_index_info.argtypes = [vp, C.POINTER(u64), C.POINTER(u32)]
-    L.real_hip_index_download.argtypes = [vp, C.c_int, vp, vp, vp]
+    L.real_hip_index_download.argtypes = [vp, C.c_int, vp, vp]
     L.real_hip_match_unique.argtypes = [vp, C.POINTER(RealHipBatch), vp, vp]
     L.real_hip_match_all.argtypes = [vp, C.POINTER(RealHipBatch), vp, u64, C.POINTER(u64), vp]
     L.real_hip_counters_get.argtypes = [vp, C.POINTER(RealHipCounters), C.c_int]

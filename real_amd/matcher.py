@@ -198,13 +198,12 @@ class HipMatcher:
         self._check(self._L.real_hip_index_info(self._h, C.byref(n), C.byref(pb)))
         self.n_entries, self.prefix_bits = int(n.value), int(pb.value)
 
-    def index_download(self, k: int):
-        n = self.n_entries
-        fp = np.zeros(n, dtype=np.uint32)
-        pos = np.zeros(n, dtype=np.uint32)
-        bkt = np.zeros((1 << self.prefix_bits) + 1, dtype=np.uint32)
-        self._check(self._L.real_hip_index_download(self._h, k, fp.ctypes.data, pos.ctypes.data, bkt.ctypes.data))
-        return fp, pos, bkt
+    def index_download(self, k: int, want_buckets: bool = True):
+        """device layout of list k: entries (n x {fingerprint, pos}) and bucket starts."""
+        ent = np.zeros((self.n_entries, 2), dtype=np.uint32)
+        bkt = np.zeros((1 << self.prefix_bits) + 1, dtype=np.uint32) if want_buckets else None
+        self._check(self._L.real_hip_index_download(self._h, k, ent.ctypes.data, _ptr(bkt)))
+        return ent, bkt
 
     # -- batches --
     @staticmethod

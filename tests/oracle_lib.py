@@ -42,7 +42,8 @@ class OraIndexStruct(C.Structure):
     _fields_ = [("seedl", C.c_uint), ("sig_bits", C.c_uint), ("shift", C.c_uint), ("n", C.c_uint64),
                 ("first_window", C.c_uint64), ("have_next", C.c_int),
                 ("sign", C.POINTER(C.c_uint64) * 6), ("ptr", C.POINTER(C.c_uint32) * 6),
-                ("pos", C.POINTER(C.c_uint32) * 6), ("lookup", C.POINTER(C.c_uint64) * 6)]
+                ("pos", C.POINTER(C.c_uint32) * 6), ("lookup", C.POINTER(C.c_uint64) * 6),
+                ("ent", C.POINTER(C.c_uint32) * 6), ("compact", C.c_int)]
 
 
 class OraGenomeStruct(C.Structure):
@@ -77,6 +78,8 @@ def lib():
         L.ora_index_build.restype = C.POINTER(OraIndexStruct)
         L.ora_index_build.argtypes = [C.POINTER(OraGenomeStruct), C.c_uint, u64, u64]
         L.ora_index_free.argtypes = [C.POINTER(OraIndexStruct)]
+        L.ora_index_from_entries.restype = C.POINTER(OraIndexStruct)
+        L.ora_index_from_entries.argtypes = [C.POINTER(OraGenomeStruct), C.c_uint, u64, C.POINTER(vp)]
         L.ora_index_getpos.restype = u32
         L.ora_index_getpos.argtypes = [C.POINTER(OraIndexStruct), C.c_int, u64]
         L.ora_get_text_word.restype = u64
@@ -184,6 +187,26 @@ class Index:
 
     def lookup(self, k: int) -> np.ndarray:
         return np.ctypeslib.as_array(self.h.contents.lookup[k], shape=(2 << 22,)).copy()
+
+
+class CompactIndex:
+    """CPU-baseline form: borrowed {sign,pos} pairs per list (seedl <= 32)."""
+
+    def __init__(self, g: Genome, seedl: int, entries):
+        self.g = g
+        self.entries = [np.ascontiguousarray(e, dtype=np.uint32) for e in entries]   # keep alive
+        self.n = int(self.entries[0].shape[0])
+        arr = (C.c_void_p * 6)(*[e.ctypes.data for e in self.entries])
+        self.h = lib().ora_index_from_entries(g.h, seedl, self.n, arr)
+        if not self.h:
+            raise ValueError("compact index needs seedl <= 32")
+        self.seedl = seedl
+        self.have_next = False
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().ora_index_free(self.h)
+            self.h = None
 
 
 def make_params(seedl=32, seedkmax=2, totalkmax=5, scores=True, filter_level=2, fileid=0, threads=0,
