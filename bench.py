@@ -85,11 +85,11 @@ def cpu_baseline(torch, m, sym_host, frag, opts, bases, qual, patl, n_reads, thr
     import oracle_lib as ora
     t0 = time.time()
     og = ora.Genome(sym_host, frag)
-    ents = []
+    signs, poss = [], []
     for k in range(6):
-        e, _ = m.index_download(k, want_buckets=False)
-        ents.append(e)
-    ix = ora.CompactIndex(og, opts.seedl, ents)
+        sg, ps = m.index_export(k)          # the sorted lists in the reference's {sign, pos} form
+        signs.append(sg); poss.append(ps)
+    ix = ora.CompactIndex(og, opts.seedl, signs, poss)
     p = ora.make_params(seedl=opts.seedl, seedkmax=opts.seedkmax, totalkmax=opts.totalkmax, scores=opts.scores,
                         filter_level=opts.filter_level, threads=threads)
     setup_s = time.time() - t0

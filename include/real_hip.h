@@ -107,8 +107,11 @@ int real_hip_build_index_block(real_hip_ctx *ctx, uint64_t first_window, uint64_
 /* introspection (tests, CPU baseline): device layout of list k               */
 int real_hip_index_info(const real_hip_ctx *ctx, uint64_t *n_entries, uint32_t *prefix_bits);
 int real_hip_index_download(real_hip_ctx *ctx, int list,
-                            uint32_t *entries      /* n_entries x {fingerprint, pos}, nullable */,
-                            uint32_t *bucket_start /* 2^prefix_bits + 1, nullable          */);
+                            uint32_t *entries      /* n_entries x {key, pos} (raw device layout), nullable */,
+                            uint32_t *bucket_start /* 2^prefix_bits + 1, nullable                        */);
+/* list k in the reference's own form: sign[j] (sig_bytes each) and pos[j] of
+ * the sorted Mask entries (Mask.hpp:22-64); either pointer may be NULL.       */
+int real_hip_index_export(real_hip_ctx *ctx, int list, void *sign, uint32_t *pos);
 
 /* ---- read batch: a decoded pattern block (PatternBlock / FastSubDecoder::
  * fillPatternBlock, FastSubDecoder.hpp:107-161): mapped symbols A,C,G,T->0..3,

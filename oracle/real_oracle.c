@@ -300,7 +300,8 @@ ora_index *ora_index_build(const ora_genome *g, unsigned l, uint64_t first_windo
     return ix;
 }
 /* compact form: see real_oracle.h */
-ora_index *ora_index_from_entries(const ora_genome *g, unsigned l, uint64_t n, const uint32_t *const ent[6])
+ora_index *ora_index_from_entries(const ora_genome *g, unsigned l, uint64_t n, const uint32_t *const sign[6],
+                                  const uint32_t *const pos[6])
 {
     (void)g;
     if (l < 4 || l > 32 || (l % 4)) return NULL;
@@ -309,19 +310,19 @@ ora_index *ora_index_from_entries(const ora_genome *g, unsigned l, uint64_t n, c
     ix->shift = (l >= ORA_SAMPLE_BITS) ? (l - ORA_SAMPLE_BITS) : 0;
     uint64_t histsize = (uint64_t)1 << ORA_SAMPLE_BITS;
     for (int k = 0; k < 6; ++k) {
-        ix->ent[k] = ent[k];
+        ix->csign[k] = sign[k]; ix->cpos[k] = pos[k];
         uint64_t *h = (uint64_t *)calloc(2 * histsize, sizeof(uint64_t));
-        const uint32_t *E = ent[k];
+        const uint32_t *E = sign[k];
         /* [low,high) of every non-empty prefix, [0,0) otherwise (getLookupTable.hpp:26-51) */
 #if defined(_OPENMP)
 #pragma omp parallel for schedule(static)
 #endif
         for (int64_t p = 0; p < (int64_t)histsize; ++p) {
             uint64_t key = (uint64_t)p << ix->shift, lo = 0, hi = n;
-            while (lo < hi) { uint64_t mid = lo + ((hi - lo) >> 1); if ((uint64_t)E[2 * mid] < key) lo = mid + 1; else hi = mid; }
+            while (lo < hi) { uint64_t mid = lo + ((hi - lo) >> 1); if ((uint64_t)E[mid] < key) lo = mid + 1; else hi = mid; }
             uint64_t first = lo, key2 = ((uint64_t)p + 1) << ix->shift;
             hi = n;
-            while (lo < hi) { uint64_t mid = lo + ((hi - lo) >> 1); if ((uint64_t)E[2 * mid] < key2) lo = mid + 1; else hi = mid; }
+            while (lo < hi) { uint64_t mid = lo + ((hi - lo) >> 1); if ((uint64_t)E[mid] < key2) lo = mid + 1; else hi = mid; }
             if (lo > first) { h[2 * p] = first; h[2 * p + 1] = lo; }
         }
         ix->lookup[k] = h;
@@ -542,8 +543,9 @@ static void match_list(read_ctx *r, int a, uint64_t s_a, uint64_t s_b, int inver
     uint64_t low = ix->lookup[a][2 * (uint64_t)prefix], high = ix->lookup[a][2 * (uint64_t)prefix + 1];
     /* std::equal_range on .sign */
     const uint64_t *S = ix->sign[a];
-    const uint32_t *E = ix->compact ? ix->ent[a] : NULL;
-#define SIGN_AT(i) (E ? (uint64_t)E[2 * (i)] : S[(i)])
+    const uint32_t *E = ix->compact ? ix->csign[a] : NULL;
+    const uint32_t *EP = ix->compact ? ix->cpos[a] : NULL;
+#define SIGN_AT(i) (E ? (uint64_t)E[(i)] : S[(i)])
     uint64_t lo = low, hi = high;
     while (lo < hi) { uint64_t mid = lo + ((hi - lo) >> 1); r->c->probes++; if (SIGN_AT(mid) < s_a) lo = mid + 1; else hi = mid; }
     uint64_t eq_lo = lo; hi = high;
@@ -556,7 +558,7 @@ static void match_list(read_ctx *r, int a, uint64_t s_a, uint64_t s_b, int inver
         uint64_t partner;
         if (E) { /* list_b[p->ptr].sign = the other two segments of the window at pos */
             unsigned syms = ix->seedl / 4;
-            uint64_t wp = E[2 * q + 1];
+            uint64_t wp = EP[q];
             partner = (ora_get_text_word(g, wp + (uint64_t)SEG_A[b] * syms, syms) << (2 * syms)) |
                       ora_get_text_word(g, wp + (uint64_t)SEG_C[b] * syms, syms);
         } else
@@ -565,7 +567,7 @@ static void match_list(read_ctx *r, int a, uint64_t s_a, uint64_t s_b, int inver
                                               : ora_diffcountpair64(s_b, partner);
         if (seedk <= p->seedkmax) {
             r->c->seedpass++;
-            uint32_t rpos = E ? E[2 * q + 1] : ora_index_getpos(ix, a, q);
+            uint32_t rpos = E ? EP[q] : ora_index_getpos(ix, a, q);
             if (rpos >= matchoffset) {
                 uint32_t pos = rpos - matchoffset;
                 if (ora_is_position_valid(g, pos, r->patl) && ora_is_dontcare_free(g, pos, r->patl)) {

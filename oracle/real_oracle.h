@@ -64,7 +64,8 @@ typedef struct ora_index {
     uint32_t *ptr[6];        /* index of the same window in list 5-k          */
     uint32_t *pos[6];        /* window start; lists 0..2 own it, 3..5 = NULL  */
     uint64_t *lookup[6];     /* 2 * 2^22 entries: [low,high) per prefix       */
-    const uint32_t *ent[6];  /* compact form only: borrowed {sign,pos} pairs   */
+    const uint32_t *csign[6]; /* compact form only: borrowed sorted signatures  */
+    const uint32_t *cpos[6];  /* compact form only: borrowed window starts      */
     int       compact;
 } ora_index;
 
@@ -74,7 +75,7 @@ typedef struct ora_index {
  * match.hpp:386 is re-read from the text window at pos (same value).  The
  * 22-bit lookup tables are rebuilt with getLookupTable's semantics.           */
 struct ora_index *ora_index_from_entries(const ora_genome *g, unsigned seedl, uint64_t n,
-                                         const uint32_t *const ent[6]);
+                                         const uint32_t *const sign[6], const uint32_t *const pos[6]);
 
 /* block = windows [first_window, first_window + max_entries) in text order   */
 ora_index *ora_index_build(const ora_genome *g, unsigned seedl,

@@ -88,12 +88,13 @@ uint32_t rh_choose_prefix_bits(const real_hip_ctx *ctx, uint64_t n_entries)
 {
     uint32_t l = ctx->prm.seedl;
     uint32_t pb = ctx->prm.prefix_bits;
-    if (!pb) { // auto: mean bucket of 4..8 entries, at most 2^28 buckets (1 GiB of starts per list)
+    if (!pb) { // auto: mean bucket of 2..4 entries (the first two entries of every bucket are prefetched
+               // together with one round trip), at most 2^30 buckets (4 GiB of starts per list)
         uint32_t lg = 0;
         while ((1ull << (lg + 1)) <= (n_entries ? n_entries : 1)) lg++;
-        pb = lg > 2 ? lg - 2 : 1;
+        pb = lg > 1 ? lg - 1 : 1;
         if (pb < 8) pb = 8;
-        if (pb > 28) pb = 28;
+        if (pb > 30) pb = 30;
     }
     if (pb > l) pb = l; // a signature has seedl bits (two segments of seedl/4 bases)
     if (pb > 30) pb = 30;
@@ -101,14 +102,43 @@ uint32_t rh_choose_prefix_bits(const real_hip_ctx *ctx, uint64_t n_entries)
     return pb;
 }
 
+__device__ __forceinline__ uint64_t dev_text_bits(const uint64_t *__restrict__ T, uint64_t i, unsigned nb)
+{
+    uint64_t w = i >> 5;
+    unsigned sh = 2u * (unsigned)(i & 31);
+    uint64_t v = T[w] << sh;
+    if (sh + 2 * nb > 64) v |= T[w + 1] >> (64 - sh);
+    return v >> (64 - 2 * nb);
+}
+
+// signature of list `list` of the window at text position p (MapTextFile::readLists, MapTextFile.hpp:211-216)
+__device__ __forceinline__ uint64_t window_signature(const uint64_t *__restrict__ T, uint64_t p, uint32_t l, int list)
+{
+    const uint32_t q = l >> 2, bb = 2 * q;
+    const int sa_seg = (list < 3) ? 0 : (list < 5) ? 1 : 2;
+    const int sc_seg = (list == 0) ? 1 : (list == 1 || list == 3) ? 2 : 3;
+    return (dev_text_bits(T, p + (uint64_t)sa_seg * q, q) << bb) | dev_text_bits(T, p + (uint64_t)sc_seg * q, q);
+}
+
+// entry j of the device list: {signature bits below the bucket prefix | top bits of the partner
+// signature, window start}.  The partner signature list_b[p->ptr].sign (match.hpp:386) is the
+// signature of list 5-k of the same window; keeping its top bits lets the matcher discard nearly
+// every chance candidate (seed popcount filter on the known symbols) without touching the text.
 template <typename K>
-__global__ void entries_kernel(const K *__restrict__ sign, const uint32_t *__restrict__ pos, uint64_t n, uint32_t pshift,
-                               uint32_t fshift, uint32_t nbuckets, uint2 *__restrict__ ent, uint32_t *__restrict__ bkt)
+__global__ void entries_kernel(const K *__restrict__ sign, const uint32_t *__restrict__ pos, uint64_t n, uint32_t l,
+                               int list, const uint64_t *__restrict__ T, uint32_t pshift, uint32_t fshift, uint32_t fbits,
+                               uint32_t pbits, uint32_t nbuckets, uint2 *__restrict__ ent, uint32_t *__restrict__ bkt)
 {
     uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    uint64_t s = (uint64_t)sign[j];
-    ent[j] = make_uint2((uint32_t)(s >> fshift), pos[j]);
+    const uint64_t s = (uint64_t)sign[j];
+    const uint32_t wp = pos[j];
+    uint64_t x = (s >> fshift) & ((fbits >= 32) ? 0xffffffffull : ((1ull << fbits) - 1));
+    if (pbits) {
+        const uint64_t partner = window_signature(T, wp, l, 5 - list);
+        x = (x << pbits) | (partner >> (l - pbits));
+    }
+    ent[j] = make_uint2((uint32_t)x, wp);
     uint32_t p = (uint32_t)(s >> pshift);
     int64_t pprev = j ? (int64_t)(uint32_t)((uint64_t)sign[j - 1] >> pshift) : -1;
     // bucket q starts at the first entry whose prefix is >= q (getLookupTable.hpp:26-51 keeps
@@ -122,7 +152,8 @@ int rh_index_from_sorted(real_hip_ctx *ctx, int list, const void *d_sign, const 
                          unsigned sig_bytes)
 {
     const uint32_t l = ctx->prm.seedl, pb = ctx->pb;
-    const uint32_t pshift = l - pb, fshift = (l > pb + 32) ? (l - pb - 32) : 0;
+    uint32_t pshift, fshift, fbits, pbits;
+    rh_index_geometry(l, pb, &pshift, &fshift, &fbits, &pbits);
     const uint32_t nb = 1u << pb;
     int rc = rh_reserve(ctx, ctx->ent[list], (n ? n : 1) * sizeof(uint2));
     if (rc) return rc;
@@ -133,12 +164,13 @@ int rh_index_from_sorted(real_hip_ctx *ctx, int list, const void *d_sign, const 
         return REAL_HIP_OK;
     }
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    const uint64_t *T = (const uint64_t *)ctx->text.p;
     if (sig_bytes == 4)
-        hipLaunchKernelGGL(entries_kernel<uint32_t>, grid, block, 0, ctx->stream, (const uint32_t *)d_sign, d_pos, n, pshift,
-                           fshift, nb, (uint2 *)ctx->ent[list].p, (uint32_t *)ctx->bkt[list].p);
+        hipLaunchKernelGGL(entries_kernel<uint32_t>, grid, block, 0, ctx->stream, (const uint32_t *)d_sign, d_pos, n, l, list, T,
+                           pshift, fshift, fbits, pbits, nb, (uint2 *)ctx->ent[list].p, (uint32_t *)ctx->bkt[list].p);
     else
-        hipLaunchKernelGGL(entries_kernel<uint64_t>, grid, block, 0, ctx->stream, (const uint64_t *)d_sign, d_pos, n, pshift,
-                           fshift, nb, (uint2 *)ctx->ent[list].p, (uint32_t *)ctx->bkt[list].p);
+        hipLaunchKernelGGL(entries_kernel<uint64_t>, grid, block, 0, ctx->stream, (const uint64_t *)d_sign, d_pos, n, l, list, T,
+                           pshift, fshift, fbits, pbits, nb, (uint2 *)ctx->ent[list].p, (uint32_t *)ctx->bkt[list].p);
     RH_HIP(ctx, hipGetLastError());
     return REAL_HIP_OK;
 }
@@ -169,29 +201,14 @@ __global__ void iota_kernel(uint32_t *out, uint64_t first, uint64_t n)
     if (i < n) out[i] = (uint32_t)(first + i);
 }
 
-__device__ __forceinline__ uint64_t dev_text_bits(const uint64_t *__restrict__ T, uint64_t i, unsigned nb)
-{
-    uint64_t w = i >> 5;
-    unsigned sh = 2u * (unsigned)(i & 31);
-    uint64_t v = T[w] << sh;
-    if (sh + 2 * nb > 64) v |= T[w + 1] >> (64 - sh);
-    return v >> (64 - 2 * nb);
-}
-
-// list k signature of the window at wpos[j] (MapTextFile::readLists, MapTextFile.hpp:211-216)
+// list k signature of the window at wpos[j]
 template <typename K>
 __global__ void keys_kernel(const uint64_t *__restrict__ T, const uint32_t *__restrict__ wpos, uint64_t n, uint32_t l,
                             int list, K *__restrict__ keys)
 {
     uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    const uint32_t q = l >> 2, bb = 2 * q;
-    const int sa_seg = (list < 3) ? 0 : (list < 5) ? 1 : 2;
-    const int sc_seg = (list == 0) ? 1 : (list == 1 || list == 3) ? 2 : 3;
-    uint64_t p = wpos[j];
-    uint64_t ma = dev_text_bits(T, p + (uint64_t)sa_seg * q, q);
-    uint64_t mc = dev_text_bits(T, p + (uint64_t)sc_seg * q, q);
-    keys[j] = (K)((ma << bb) | mc);
+    keys[j] = (K)window_signature(T, wpos[j], l, list);
 }
 
 template <typename K>
@@ -353,5 +370,42 @@ int rh_all_finish(real_hip_ctx *ctx, uint64_t n_raw, uint64_t n_reads, real_hip_
         hipLaunchKernelGGL(all_offsets_kernel, dim3((unsigned)((n_reads + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
                            (const real_hip_hit *)d_out, n_raw, n_reads, d_hit_offsets);
     RH_HIP(ctx, hipGetLastError());
+    return REAL_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// export of a device list in the reference's form {signature, position} (tests, CPU baseline)
+// ---------------------------------------------------------------------------
+template <typename K>
+__global__ void export_kernel(const uint2 *__restrict__ ent, const uint64_t *__restrict__ T, uint64_t n, uint32_t l, int list,
+                              K *__restrict__ sign, uint32_t *__restrict__ pos)
+{
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t p = ent[j].y;
+    sign[j] = (K)window_signature(T, p, l, list);
+    pos[j] = p;
+}
+
+int rh_index_export(real_hip_ctx *ctx, int list, void *h_sign, uint32_t *h_pos)
+{
+    const uint64_t n = ctx->n_entries;
+    if (!n) return REAL_HIP_OK;
+    const uint32_t l = ctx->prm.seedl;
+    const unsigned sb = l <= 32 ? 4 : 8;
+    int rc;
+    if ((rc = rh_reserve(ctx, ctx->keys_a, n * sb))) return rc;
+    if ((rc = rh_reserve(ctx, ctx->vals_a, n * 4))) return rc;
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (sb == 4)
+        hipLaunchKernelGGL(export_kernel<uint32_t>, grid, block, 0, ctx->stream, (const uint2 *)ctx->ent[list].p,
+                           (const uint64_t *)ctx->text.p, n, l, list, (uint32_t *)ctx->keys_a.p, (uint32_t *)ctx->vals_a.p);
+    else
+        hipLaunchKernelGGL(export_kernel<uint64_t>, grid, block, 0, ctx->stream, (const uint2 *)ctx->ent[list].p,
+                           (const uint64_t *)ctx->text.p, n, l, list, (uint64_t *)ctx->keys_a.p, (uint32_t *)ctx->vals_a.p);
+    RH_HIP(ctx, hipGetLastError());
+    if (h_sign) RH_HIP(ctx, hipMemcpyAsync(h_sign, ctx->keys_a.p, n * sb, hipMemcpyDeviceToHost, ctx->stream));
+    if (h_pos) RH_HIP(ctx, hipMemcpyAsync(h_pos, ctx->vals_a.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return REAL_HIP_OK;
 }

@@ -1,0 +1,409 @@
+// match_kernel.hip -- the per-read matcher of REAL as one hand-written gfx950 kernel
+// (SURVEY 8a rows a6..a12):
+//   bucket lookup + in-bucket search        match.hpp:376-381
+//   seed popcount filter                    match.hpp:383-388, PopCountTable.hpp:113-131
+//   position / fragment / N checks          match.hpp:390-398
+//   Hamming verify                          RestMatch.hpp:39-81
+//   quality aware score                     ComputeScore.hpp:50-190
+//   best/unique fold                        matchUniqueImplementation.cpp:97-160, 179-248
+//   or hit append of matchAll               matchAllImplementation.cpp:172-184
+//
+// Work decomposition: one lane per read, 256-thread workgroups.  For each strand the lane
+//   1. issues the bucket-table loads of all lists of the strand together,
+//   2. issues the loads of the first two entries of every bucket together,
+//   3. scans the buckets in list order and pushes the entries whose fingerprint matches
+//      into a small per-lane queue in LDS (list-major, entry order = the reference's
+//      candidate order),
+//   4. drains the queue in order: seed window from the 2-bit text, popcount filters, whole
+//      read Hamming distance, score, and the fold (or the matchAll append).
+// The update() events of a read therefore reach the fold in the canonical order (strand,
+// list, position), which matters because the fold is order dependent when scores are on
+// (SURVEY 8a10).  Every memory access of the kernel is a dependent random 8..40-byte read of
+// an HBM-resident table: the kernel is bound by the number of dependent round trips a wave
+// makes and by HBM sector throughput, not by arithmetic (no MFMA: XOR/popcount and a short
+// FP64 add chain).  Batching the loads (steps 1, 2) and queueing the candidates (step 3)
+// are what keep the number of sequential round trips per wave small.
+#include "kernel_common.h"
+
+#define MQ 16 // candidate queue slots per lane (LDS); a full queue is drained and refilled
+
+template <int W, bool SCORES, bool ALL>
+struct LaneState {
+    // read
+    uint64_t O[W];      // oriented read, 32 bases per word
+    uint64_t shi, slo;  // seed halves (m0|m1), (m2|m3) of the oriented read
+    uint32_t patl, nw, so;
+    uint64_t lastmask;
+    float eps;
+    int inv;
+    uint64_t r;
+    // result
+    uint64_t info;
+    float iscore;
+    // memo of the last verified position of this strand: the same window is reached through
+    // up to six lists; its verdict is a function of (strand,pos) only
+    uint32_t cpos, ck, cfrag;
+    float cscore;
+    bool cok;
+    uint32_t crpos, ckk; // last seed window looked at and its per-segment mismatch counts (4 x 8 bits)
+    // work counters
+    unsigned cL, cP, cC, cS, cH, cV;
+};
+
+// one member of a bucket whose fingerprint equals the read's: the body of the candidate loop
+// of ::match (match.hpp:383-413)
+template <int W, bool SCORES, bool ALL>
+__device__ __forceinline__ void process_candidate(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL,
+                                                  uint32_t rpos, int la)
+{
+    const uint64_t *__restrict__ T = a.t.text;
+    const uint32_t bb = a.b_bits, half = a.l >> 1;
+    const uint64_t mb = (bb >= 64) ? ~0ull : ((1ull << bb) - 1);
+    // seed window of the genome at rpos, as the two halves (m0|m1), (m2|m3); per-segment mismatch
+    // counts are a function of (strand, rpos) only and are memoised: the true locus is reached
+    // through up to six lists in a row
+    if (rpos != s.crpos) {
+        const uint64_t xhi = text_bits(T, rpos, half) ^ s.shi;
+        const uint64_t xlo = text_bits(T, (uint64_t)rpos + half, half) ^ s.slo;
+        const uint64_t dhi = ((xhi >> 1) | xhi) & M55, dlo = ((xlo >> 1) | xlo) & M55;
+        s.ckk = __popcll(dhi >> bb) | (__popcll(dhi & mb) << 8) | (__popcll(dlo >> bb) << 16) | (__popcll(dlo & mb) << 24);
+        s.crpos = rpos;
+    }
+    const unsigned k0 = s.ckk & 0xff, k1 = (s.ckk >> 8) & 0xff, k2 = (s.ckk >> 16) & 0xff, k3 = s.ckk >> 24;
+    // the two segments list la is keyed on (s0..s5 = (0,1),(0,2),(0,3),(1,2),(1,3),(2,3))
+    const unsigned ka = (la < 3) ? k0 : (la < 5) ? k1 : k2;
+    const unsigned kc = (la == 0) ? k1 : (la == 1 || la == 3) ? k2 : k3;
+    if (ka | kc) return; // not a member of the reference's equal range (signature wider than prefix+32)
+    if (!a.ix.pbits) s.cC++; // (with partner bits the entry holds the whole signature: counted at the scan)
+    const unsigned seedk = k0 + k1 + k2 + k3; // = diffcountpair(s_b, list_b[p->ptr].sign), match.hpp:386
+    if (seedk > a.seedkmax) return;
+    s.cS++;
+    if (rpos < s.so) return; // match.hpp:393
+    const uint32_t pos = rpos - s.so;
+    if (pos != s.cpos) {
+        s.cpos = pos;
+        s.cok = false;
+        s.cV++;
+        uint32_t frag;
+        if (!frag_valid(a.t, pos, s.patl, frag)) return;
+        if (a.t.has_wild && !wild_free(a.t.wild, pos, s.patl)) return;
+        // Hamming distance of the whole oriented read against text[pos, pos+patl)
+        // = seedk + RestMatch::computeDistance (RestMatch.hpp:39-81)
+        const uint64_t wi = pos >> 5;
+        const unsigned sh = 2u * (pos & 31);
+        uint64_t tw[W];
+        unsigned total = 0;
+        {
+            uint64_t t[W + 1];
+#pragma unroll
+            for (int j = 0; j <= W; ++j) t[j] = ((uint32_t)j <= s.nw) ? T[wi + j] : 0ull; // all loads in flight together
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                uint64_t al = sh ? ((t[j] << sh) | (t[j + 1] >> (64 - sh))) : t[j];
+                tw[j] = al;
+                uint64_t x = al ^ s.O[j];
+                uint64_t d = ((x >> 1) | x) & M55;
+                if ((uint32_t)j + 1 == s.nw) d &= s.lastmask;
+                if ((uint32_t)j < s.nw) total += __popcll(d);
+            }
+        }
+        if (total > a.totalkmax) return;
+        float sc = 1.0f; // ComputeScore<...,false>, ComputeScore.hpp:31-45
+        if (SCORES) {
+            // ComputeScore<...,true>::computeScore, ComputeScore.hpp:50-190: sequential FP64 sum in
+            // base order starting at 1.0, cast to float once.
+            double raw = 1.0;
+            const uint8_t *__restrict__ qp = a.b.qrows + s.r * (2ull * a.b.QS) + (uint64_t)s.inv * a.b.QS;
+            // 16 bases per step in a real (not unrolled) loop: the adds are one dependent chain, and a fully
+            // unrolled body lets the scheduler hoist every table read in front of it (1 wave per SIMD).  The
+            // per-step operands sit in registers and are rotated down by one slot per step, which keeps all
+            // register indices static.
+            constexpr int NQ = 2 * W;
+            uint32_t th[NQ], oh[NQ];
+#pragma unroll
+            for (int c = 0; c < NQ; ++c) {
+                th[c] = (uint32_t)(tw[c >> 1] >> ((c & 1) ? 0 : 32));
+                oh[c] = (uint32_t)(s.O[c >> 1] >> ((c & 1) ? 0 : 32));
+            }
+            constexpr bool BATCHQ = (W <= 4); // short reads: all quality chunks in flight together (one round trip)
+            uint4 qv[BATCHQ ? NQ : 1];
+            if (BATCHQ) {
+#pragma unroll
+                for (int c = 0; c < NQ; ++c)
+                    qv[c] = (16u * c < s.patl) ? *reinterpret_cast<const uint4 *>(qp + 16 * c) : make_uint4(0, 0, 0, 0);
+            }
+            const uint32_t nchunk = (s.patl + 15) >> 4;
+#pragma unroll 1
+            for (uint32_t c = 0; c < nchunk; ++c) {
+                const uint4 q4 = BATCHQ ? qv[0] : *reinterpret_cast<const uint4 *>(qp + 16 * c);
+                const uint32_t qa[4] = {q4.x, q4.y, q4.z, q4.w};
+                const uint32_t lim = min(16u, s.patl - 16u * c);
+                const uint32_t tr = th[0], rr = oh[0];
+#pragma unroll
+                for (uint32_t u = 0; u < 16; ++u) {
+                    if (u < lim) {
+                        const uint32_t ref = (tr >> (30 - 2 * u)) & 3;
+                        const uint32_t rb = (rr >> (30 - 2 * u)) & 3;
+                        const uint32_t q = (qa[u >> 2] >> (8 * (u & 3))) & 0xff;
+                        raw += sLL[((ref << 8) | (rb << 6) | q) & 1023];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i + 1 < NQ; ++i) {
+                    th[i] = th[i + 1]; oh[i] = oh[i + 1];
+                    if (BATCHQ) qv[i] = qv[i + 1];
+                }
+            }
+            sc = (float)raw;
+        }
+        s.cok = true; s.ck = total; s.cscore = sc; s.cfrag = frag;
+    }
+    if (!s.cok) return;
+    s.cH++; // one updater::update call, match.hpp:411
+    if (ALL) {
+        // unifyMatches (matchAllImplementation.cpp:150-161) only removes exact duplicates: the same
+        // (strand,pos) reached through a later list.  A hit is kept iff la is the first list whose two
+        // segments are mismatch free.
+        const bool z0 = !k0, z1 = !k1, z2 = !k2, z3 = !k3;
+        const int first = (z0 && z1) ? 0 : (z0 && z2) ? 1 : (z0 && z3) ? 2 : (z1 && z2) ? 3 : (z1 && z3) ? 4 : 5;
+        if (first == la) {
+            unsigned long long slot = wave_append_slot(a.raw_count);
+            if (slot < a.raw_cap)
+                a.raw[slot] = make_uint4((uint32_t)s.r, s.cpos, __float_as_uint(s.cscore),
+                                         s.ck | ((uint32_t)s.inv << 8) | (s.cfrag << 16));
+        }
+    } else {
+        fold_update<SCORES>(s.inv != 0, a.t.fileid, s.cpos, s.ck, s.cscore, s.eps, s.cfrag, s.info, s.iscore);
+    }
+}
+
+// Scan of the buckets of lists [LA0, LA1) of one strand; pushes the entries that survive the key
+// (and partner) comparison into the lane's LDS queue, list-major and in entry order = the reference's
+// candidate order.  FIRST = the normal, only pass: all bucket-table loads are issued together, then
+// the first two entries of every bucket together.  !FIRST = continuation after a full queue was
+// drained (repeat-rich loci only): everything is recomputed from the seed halves and the cursors
+// parked in LDS, so that no scan state has to stay in registers across the drain (occupancy).
+// Returns true if the queue filled up (again).
+template <int W, bool SCORES, bool ALL, int LA0, int LA1, bool FIRST>
+__device__ __forceinline__ bool scan_lists(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, uint32_t *q_pos, uint8_t *q_la,
+                                           uint32_t *q_cur, uint32_t &donemask, uint32_t &qn)
+{
+    const uint32_t bb = a.b_bits;
+    const uint64_t mb = (bb >= 64) ? ~0ull : ((1ull << bb) - 1);
+    const uint64_t m[4] = {s.shi >> bb, s.shi & mb, s.slo >> bb, s.slo & mb};
+    constexpr int NL = LA1 - LA0;
+    const uint32_t pbits = a.ix.pbits;
+    const uint32_t pmask = pbits ? ((1u << pbits) - 1) : 0u;
+    uint32_t fp[NL], lo[NL], hi[NL];
+    // 1. bucket starts of all lists of the strand: 2*NL independent loads
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const int la = LA0 + i;
+        const int xa = (la < 3) ? 0 : (la < 5) ? 1 : 2, xc = (la == 0) ? 1 : (la == 1 || la == 3) ? 2 : 3;
+        const uint64_t sa = (m[xa] << bb) | m[xc]; // s_a of list la, SignatureConstruction.hpp:62-67
+        const uint32_t prefix = (uint32_t)(sa >> a.ix.pshift);
+        fp[i] = (uint32_t)((sa >> a.ix.fshift) & ((a.ix.fbits >= 32) ? 0xffffffffull : ((1ull << a.ix.fbits) - 1)));
+        const uint32_t *__restrict__ bk = a.ix.bkt[la];
+        lo[i] = bk[prefix];
+        hi[i] = bk[prefix + 1];
+    }
+    // 2. first two entries of every bucket: 2*NL independent loads
+    uint2 e0[NL], e1[NL];
+    uint32_t cur[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const uint2 *__restrict__ E = a.ix.ent[LA0 + i];
+        if (FIRST) {
+            e0[i] = (lo[i] < hi[i]) ? E[lo[i]] : make_uint2(0xffffffffu, 0);
+            e1[i] = (lo[i] + 1 < hi[i]) ? E[lo[i] + 1] : make_uint2(0xffffffffu, 0);
+        } else {
+            e0[i] = e1[i] = make_uint2(0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        if (FIRST) {
+            s.cL++;
+            cur[i] = lo[i];
+            if (hi[i] - lo[i] > 16) { // large bucket: lower_bound on the key first
+                const uint2 *__restrict__ E = a.ix.ent[LA0 + i];
+                uint32_t x = lo[i], y = hi[i];
+                while (x < y) {
+                    uint32_t mid = x + ((y - x) >> 1);
+                    s.cP++;
+                    if ((E[mid].x >> pbits) < fp[i]) x = mid + 1; else y = mid;
+                }
+                cur[i] = x;
+            }
+        } else {
+            cur[i] = q_cur[i * 256 + threadIdx.x];
+        }
+    }
+    // 3. scan in list order, queue the survivors
+    bool again = false;
+    qn = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        if (!again && !(donemask & (1u << i))) {
+            const uint2 *__restrict__ E = a.ix.ent[LA0 + i];
+            const uint32_t f = fp[i], h = hi[i];
+            // top pbits of the read's partner signature s_b (the signature of list 5-la)
+            const int lb = 5 - (LA0 + i);
+            const int xb = (lb < 3) ? 0 : (lb < 5) ? 1 : 2, xd = (lb == 0) ? 1 : (lb == 1 || lb == 3) ? 2 : 3;
+            const uint32_t rp = pbits ? (uint32_t)(((m[xb] << bb) | m[xd]) >> (a.l - pbits)) : 0u;
+            uint32_t j = cur[i];
+            while (j < h) {
+                if (qn == MQ) { again = true; break; }
+                uint2 e;
+                if (FIRST && j == lo[i]) e = e0[i];
+                else if (FIRST && j == lo[i] + 1) e = e1[i];
+                else e = E[j];
+                s.cP++;
+                const uint32_t ek = e.x >> pbits;
+                if (ek > f) { j = h; break; }
+                if (ek == f) {
+                    bool keep = true;
+                    if (pbits) {
+                        // member of the reference's equal range; seed popcount filter (match.hpp:386) on the
+                        // partner symbols the entry carries: more than seedkmax known mismatches => rejected
+                        // without touching the text (exact: the full count can only be larger)
+                        s.cC++;
+                        const uint32_t x = (e.x & pmask) ^ rp;
+                        keep = __popc(((x >> 1) | x) & 0x55555555u) <= a.seedkmax;
+                    }
+                    if (keep) {
+                        q_pos[qn * 256 + threadIdx.x] = e.y;
+                        q_la[qn * 256 + threadIdx.x] = (uint8_t)(LA0 + i);
+                        qn++;
+                    }
+                }
+                j++;
+            }
+            cur[i] = j;
+            if (!again) donemask |= 1u << i;
+        }
+    }
+    if (again) { // park the cursors in LDS; the continuation pass reloads them
+#pragma unroll
+        for (int i = 0; i < NL; ++i) q_cur[i * 256 + threadIdx.x] = cur[i];
+    }
+    return again;
+}
+
+// lists [LA0, LA1) of one strand
+template <int W, bool SCORES, bool ALL, int LA0, int LA1>
+__device__ __forceinline__ void match_lists(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL,
+                                            uint32_t *q_pos, uint8_t *q_la, uint32_t *q_cur)
+{
+    uint32_t donemask = 0, qn = 0;
+    bool again = scan_lists<W, SCORES, ALL, LA0, LA1, true>(a, s, q_pos, q_la, q_cur, donemask, qn);
+    // 4. verify / score / fold in candidate order
+    for (uint32_t k = 0; k < qn; ++k)
+        process_candidate<W, SCORES, ALL>(a, s, sLL, q_pos[k * 256 + threadIdx.x], (int)q_la[k * 256 + threadIdx.x]);
+    while (again) {
+        again = scan_lists<W, SCORES, ALL, LA0, LA1, false>(a, s, q_pos, q_la, q_cur, donemask, qn);
+        for (uint32_t k = 0; k < qn; ++k)
+            process_candidate<W, SCORES, ALL>(a, s, sLL, q_pos[k * 256 + threadIdx.x], (int)q_la[k * 256 + threadIdx.x]);
+    }
+}
+
+template <int W, bool SCORES, bool ALL>
+__global__ __launch_bounds__(256) void match_kernel(MatchArgs a)
+{
+    __shared__ double sLL[SCORES ? 1024 : 1];
+    __shared__ uint32_t q_pos[MQ * 256];
+    __shared__ uint8_t q_la[MQ * 256];
+    __shared__ uint32_t q_cur[6 * 256];
+    if (SCORES) {
+        for (int i = threadIdx.x; i < 1024; i += 256) sLL[i] = a.LL[i];
+        __syncthreads();
+    }
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    LaneState<W, SCORES, ALL> s;
+    s.cL = s.cP = s.cC = s.cS = s.cH = s.cV = 0;
+    unsigned cR = 0;
+    const uint32_t patl = (r < a.b.n_reads) ? a.b.patl[r] : 0u;
+
+    if (patl) {
+        cR = 1;
+        s.r = r; s.patl = patl;
+        s.nw = (patl + 31) >> 5;
+        s.lastmask = ~0ull << (64 - 2 * (patl - 32 * (s.nw - 1)));
+        s.eps = (float)(a.filter_mult * (double)patl); // RealOptions.hpp:74-77
+        s.info = 0; s.iscore = 0.f;
+        if (!ALL) {
+            s.info = a.info[r];
+            if (SCORES) s.iscore = a.score[r];
+        }
+        for (int inv = 0; inv < 2; ++inv) {
+            const uint64_t *wp = a.b.words + r * (2 * W) + inv * W;
+#pragma unroll
+            for (int j = 0; j < W; ++j) s.O[j] = wp[j];
+            s.shi = a.b.seeds[r * 4 + inv * 2];
+            s.slo = a.b.seeds[r * 4 + inv * 2 + 1];
+            s.inv = inv;
+            s.so = inv ? (patl - a.l) : 0u; // RestMatch::getMatchOffset, RestMatch.hpp:84-89
+            s.cpos = 0xffffffffu; s.ck = 0; s.cfrag = 0; s.cscore = 1.0f; s.cok = false;
+            s.crpos = 0xffffffffu; s.ckk = 0;
+            if (!ALL && !SCORES) {
+                // uni0s / uni0r early-out (matchUniqueImplementation.cpp:434-436, 470-472): lists 1..5 of a
+                // strand are skipped when list 0 left the record in this strand's state with 0 errors
+                match_lists<W, SCORES, ALL, 0, 1>(a, s, sLL, q_pos, q_la, q_cur);
+                const unsigned st = (unsigned)(s.info >> ST_SHIFT), er = (unsigned)(s.info >> ER_SHIFT) & 15;
+                if (!(st == (unsigned)(inv ? ST_REVERSE : ST_STRAIGHT) && er == 0))
+                    match_lists<W, SCORES, ALL, 1, 6>(a, s, sLL, q_pos, q_la, q_cur);
+            } else {
+                match_lists<W, SCORES, ALL, 0, 6>(a, s, sLL, q_pos, q_la, q_cur);
+            }
+        }
+        if (!ALL) {
+            a.info[r] = s.info;
+            if (SCORES) a.score[r] = s.iscore;
+        }
+    }
+
+    // work counters: wave reduction, one atomic per wave and counter
+    unsigned c[7] = {cR, s.cL, s.cP, s.cC, s.cS, s.cH, s.cV};
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        unsigned v = c[k];
+        for (int d = 32; d; d >>= 1) v += __shfl_xor((int)v, d);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(a.counters + k, (unsigned long long)v);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// launcher
+// ---------------------------------------------------------------------------
+template <int W>
+static void launch_match_w(real_hip_ctx *ctx, const MatchArgs &a, bool all)
+{
+    dim3 grid((unsigned)((a.b.n_reads + 255) / 256)), block(256);
+    const bool sc = ctx->prm.scores != 0;
+    if (all) {
+        if (sc) hipLaunchKernelGGL((match_kernel<W, true, true>), grid, block, 0, ctx->stream, a);
+        else    hipLaunchKernelGGL((match_kernel<W, false, true>), grid, block, 0, ctx->stream, a);
+    } else {
+        if (sc) hipLaunchKernelGGL((match_kernel<W, true, false>), grid, block, 0, ctx->stream, a);
+        else    hipLaunchKernelGGL((match_kernel<W, false, false>), grid, block, 0, ctx->stream, a);
+    }
+}
+
+int rh_launch_match(real_hip_ctx *ctx, const MatchArgs &a, bool all)
+{
+    if (!a.b.n_reads) return REAL_HIP_OK;
+    RhTimer tm(ctx, all ? REAL_HIP_K_MATCH_ALL : REAL_HIP_K_MATCH_UNIQUE);
+    switch (a.b.W) {
+    case 1: launch_match_w<1>(ctx, a, all); break;
+    case 2: launch_match_w<2>(ctx, a, all); break;
+    case 3: launch_match_w<3>(ctx, a, all); break;
+    case 4: launch_match_w<4>(ctx, a, all); break;
+    case 5: launch_match_w<5>(ctx, a, all); break;
+    case 6: launch_match_w<6>(ctx, a, all); break;
+    case 7: launch_match_w<7>(ctx, a, all); break;
+    case 8: launch_match_w<8>(ctx, a, all); break;
+    default: return rh_fail(ctx, REAL_HIP_E_UNSUPPORTED, "read longer than REAL_HIP_MAX_PATL", hipSuccess);
+    }
+    RH_HIP(ctx, hipGetLastError());
+    return REAL_HIP_OK;
+}

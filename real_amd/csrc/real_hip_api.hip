@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -300,6 +301,17 @@ extern "C" int real_hip_index_download(real_hip_ctx *ctx, int list, uint32_t *en
     return REAL_HIP_OK;
 }
 
+int rh_index_export(real_hip_ctx *ctx, int list, void *h_sign, uint32_t *h_pos);
+extern "C" int real_hip_index_export(real_hip_ctx *ctx, int list, void *sign, uint32_t *pos)
+{
+    RH_ENTER(ctx);
+    if (!ctx->have_index) return rh_fail(ctx, REAL_HIP_E_STATE, "no index", hipSuccess);
+    if (list < 0 || list > 5) return rh_fail(ctx, REAL_HIP_E_INVALID, "list", hipSuccess);
+    int rc = rh_index_export(ctx, list, sign, pos);
+    rh_release(ctx->keys_a); rh_release(ctx->vals_a);
+    return rc;
+}
+
 // ---------------------------------------------------------------------------
 // batches
 // ---------------------------------------------------------------------------
@@ -372,7 +384,8 @@ static void fill_args(real_hip_ctx *ctx, const Staged &s, uint64_t n, MatchArgs 
     a.t.has_wild = ctx->n_wild ? 1 : 0; a.t.fileid = ctx->fileid;
     const uint32_t l = ctx->prm.seedl, pb = ctx->pb;
     for (int k = 0; k < 6; ++k) { a.ix.ent[k] = (const uint2 *)ctx->ent[k].p; a.ix.bkt[k] = (const uint32_t *)ctx->bkt[k].p; }
-    a.ix.n = ctx->n_entries; a.ix.pb = pb; a.ix.pshift = l - pb; a.ix.fshift = (l > pb + 32) ? (l - pb - 32) : 0;
+    a.ix.n = ctx->n_entries; a.ix.pb = pb;
+    rh_index_geometry(l, pb, &a.ix.pshift, &a.ix.fshift, &a.ix.fbits, &a.ix.pbits);
     a.b.words = (const uint64_t *)ctx->words.p; a.b.seeds = (const uint64_t *)ctx->seeds.p;
     a.b.qrows = (const uint8_t *)ctx->qrows.p; a.b.patl = (const uint32_t *)ctx->patl.p;
     a.b.n_reads = n; a.b.W = s.W; a.b.QS = s.QS;

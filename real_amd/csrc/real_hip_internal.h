@@ -32,9 +32,26 @@ struct DevIndex {
     const uint32_t *bkt[6]; // 2^pb + 1 bucket starts
     uint64_t n;
     uint32_t pb;     // prefix bits
-    uint32_t pshift; // sig_bits - pb
-    uint32_t fshift; // max(sig_bits - pb - 32, 0)
+    uint32_t pshift; // sig_bits - pb: prefix = sign >> pshift
+    uint32_t fshift; // entry.x = [fbits of (sign >> fshift)] [pbits of the partner signature's top bits]
+    uint32_t fbits;  // signature bits kept in the entry (all sig_bits - pb of them when that is <= 30)
+    uint32_t pbits;  // partner-signature bits kept in the entry (even; 0 when the signature needs all 32)
 };
+
+// entry geometry shared by the index build and the matcher
+static inline void rh_index_geometry(uint32_t l, uint32_t pb, uint32_t *pshift, uint32_t *fshift, uint32_t *fbits, uint32_t *pbits)
+{
+    const uint32_t R = l - pb; // signature bits below the bucket prefix
+    *pshift = R;
+    if (R <= 30) {
+        uint32_t pbts = (32 - R) & ~1u;
+        if (pbts > l) pbts = l;
+        if (pbts > 30) pbts = 30;
+        *fshift = 0; *fbits = R; *pbits = pbts;
+    } else {
+        *fshift = R - 32; *fbits = 32; *pbits = 0;
+    }
+}
 
 struct DevBatch {
     const uint64_t *words; // [n_reads][2][W]   oriented reads, 32 bases / word, MSB first

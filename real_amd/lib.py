@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "real_hip_scoring_table", "real_hip_create", "real_hip_destroy", "real_hip_strerror",
     "real_hip_last_error", "real_hip_abi_version", "real_hip_set_text", "real_hip_set_text_symbols",
     "real_hip_set_index_block", "real_hip_build_index_block", "real_hip_index_info",
-    "real_hip_index_download", "real_hip_match_unique", "real_hip_match_all",
+    "real_hip_index_download", "real_hip_index_export", "real_hip_match_unique", "real_hip_match_all",
     "real_hip_counters_get", "real_hip_kernel_time", "real_hip_timing_enable",
 ]
 
@@ -97,6 +97,7 @@ def load():
     L.real_hip_build_index_block.argtypes = [vp, u64, u64, C.POINTER(u64), C.POINTER(C.c_int)]
     L.real_hip_index_info.argtypes = [vp, C.POINTER(u64), C.POINTER(u32)]
     L.real_hip_index_download.argtypes = [vp, C.c_int, vp, vp]
+    L.real_hip_index_export.argtypes = [vp, C.c_int, vp, vp]
     L.real_hip_match_unique.argtypes = [vp, C.POINTER(RealHipBatch), vp, vp]
     L.real_hip_match_all.argtypes = [vp, C.POINTER(RealHipBatch), vp, u64, C.POINTER(u64), vp]
     L.real_hip_counters_get.argtypes = [vp, C.POINTER(RealHipCounters), C.c_int]

@@ -205,6 +205,14 @@ class HipMatcher:
         self._check(self._L.real_hip_index_download(self._h, k, ent.ctypes.data, _ptr(bkt)))
         return ent, bkt
 
+    def index_export(self, k: int):
+        """list k in the reference's form: (sign[n], pos[n]) of the sorted Mask entries."""
+        sdt = np.uint32 if self.opts.seedl <= 32 else np.uint64
+        sign = np.zeros(self.n_entries, dtype=sdt)
+        pos = np.zeros(self.n_entries, dtype=np.uint32)
+        self._check(self._L.real_hip_index_export(self._h, k, sign.ctypes.data, pos.ctypes.data))
+        return sign, pos
+
     # -- batches --
     @staticmethod
     def _batch(bases, qual, offsets, patl: int, n_reads: Optional[int], max_patl: int = 0) -> RealHipBatch:

@@ -43,7 +43,7 @@ class OraIndexStruct(C.Structure):
                 ("first_window", C.c_uint64), ("have_next", C.c_int),
                 ("sign", C.POINTER(C.c_uint64) * 6), ("ptr", C.POINTER(C.c_uint32) * 6),
                 ("pos", C.POINTER(C.c_uint32) * 6), ("lookup", C.POINTER(C.c_uint64) * 6),
-                ("ent", C.POINTER(C.c_uint32) * 6), ("compact", C.c_int)]
+                ("csign", C.POINTER(C.c_uint32) * 6), ("cpos", C.POINTER(C.c_uint32) * 6), ("compact", C.c_int)]
 
 
 class OraGenomeStruct(C.Structure):
@@ -79,7 +79,7 @@ def lib():
         L.ora_index_build.argtypes = [C.POINTER(OraGenomeStruct), C.c_uint, u64, u64]
         L.ora_index_free.argtypes = [C.POINTER(OraIndexStruct)]
         L.ora_index_from_entries.restype = C.POINTER(OraIndexStruct)
-        L.ora_index_from_entries.argtypes = [C.POINTER(OraGenomeStruct), C.c_uint, u64, C.POINTER(vp)]
+        L.ora_index_from_entries.argtypes = [C.POINTER(OraGenomeStruct), C.c_uint, u64, C.POINTER(vp), C.POINTER(vp)]
         L.ora_index_getpos.restype = u32
         L.ora_index_getpos.argtypes = [C.POINTER(OraIndexStruct), C.c_int, u64]
         L.ora_get_text_word.restype = u64
@@ -190,14 +190,16 @@ class Index:
 
 
 class CompactIndex:
-    """CPU-baseline form: borrowed {sign,pos} pairs per list (seedl <= 32)."""
+    """CPU-baseline form: borrowed sorted sign[] / pos[] per list (seedl <= 32)."""
 
-    def __init__(self, g: Genome, seedl: int, entries):
+    def __init__(self, g: Genome, seedl: int, signs, poss):
         self.g = g
-        self.entries = [np.ascontiguousarray(e, dtype=np.uint32) for e in entries]   # keep alive
-        self.n = int(self.entries[0].shape[0])
-        arr = (C.c_void_p * 6)(*[e.ctypes.data for e in self.entries])
-        self.h = lib().ora_index_from_entries(g.h, seedl, self.n, arr)
+        self.signs = [np.ascontiguousarray(e, dtype=np.uint32) for e in signs]   # keep alive
+        self.poss = [np.ascontiguousarray(e, dtype=np.uint32) for e in poss]
+        self.n = int(self.signs[0].shape[0])
+        sa = (C.c_void_p * 6)(*[e.ctypes.data for e in self.signs])
+        pa = (C.c_void_p * 6)(*[e.ctypes.data for e in self.poss])
+        self.h = lib().ora_index_from_entries(g.h, seedl, self.n, sa, pa)
         if not self.h:
             raise ValueError("compact index needs seedl <= 32")
         self.seedl = seedl

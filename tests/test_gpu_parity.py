@@ -163,6 +163,8 @@ def test_index_layout_device_equals_host(ora):
             eh, bh = h.index_download(k)
             assert np.array_equal(ea, eh) and np.array_equal(ba, bh)
             assert np.array_equal(ea[:, 1], oix.pos(k)), "device list order != reference list order"
+            sg, ps = a.index_export(k)
+            assert np.array_equal(sg.astype(np.uint64), oix.sign(k)) and np.array_equal(ps, oix.pos(k))
             # bucket table: starts are the lower bounds of the prefixes
             pref = (oix.sign(k) >> np.uint64(seedl - a.prefix_bits)).astype(np.int64)
             want = np.searchsorted(pref, np.arange((1 << a.prefix_bits) + 1), side="left")

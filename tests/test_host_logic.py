@@ -133,8 +133,7 @@ def test_compact_index_is_the_same_matcher(ora):
     b = synth.sample_reads(g, 1500, 100, 0.02, seed=6)
     og = ora.Genome(g.sym, g.frag_start)
     ix = ora.Index(og, 32)
-    ents = [np.stack([ix.sign(k).astype(np.uint32), ix.pos(k)], axis=1) for k in range(6)]
-    cix = ora.CompactIndex(og, 32, ents)
+    cix = ora.CompactIndex(og, 32, [ix.sign(k).astype(np.uint32) for k in range(6)], [ix.pos(k) for k in range(6)])
     for scores in (0, 1):
         p = ora.make_params(seedl=32, seedkmax=2, totalkmax=3, scores=scores)
         i1, s1, c1 = ora.match_unique(og, ix, p, b.bases, b.qual, b.offsets)
