@@ -135,6 +135,7 @@ def main():
     import torch.distributed as dist
     from real_amd import lib as rlib
     from real_amd.matcher import RealOptions, UniqueMatcher
+    from real_amd.distributed import gather_records
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -171,8 +172,6 @@ def main():
     torch.cuda.empty_cache()
     info = torch.zeros(n, dtype=torch.int64, device=dev)
     score = torch.empty(n, dtype=torch.float32, device=dev)
-    gather_info = [torch.empty_like(info) for _ in range(world)] if (world > 1 and rank == 0) else None
-    gather_score = [torch.empty_like(score) for _ in range(world)] if (world > 1 and rank == 0) else None
     t_setup = time.time() - t_setup
 
     def step():
@@ -180,8 +179,7 @@ def main():
         torch.cuda.current_stream().synchronize()
         m.match_unique(bases, qual, patl=args.patl, info=info, score=score, n_reads=n)
         if world > 1:                                          # the one collective: records to the root
-            dist.gather(info, gather_info, dst=0)
-            dist.gather(score, gather_score, dst=0)
+            gather_records(info, score, dst=0)
 
     for _ in range(args.warmup):
         step()

@@ -1,7 +1,8 @@
 #!/bin/bash
 # rocprofv3 recipe for bench.py (run on the GPU box through gpurun):
 #   bench_support/profile.sh <tag> [bench args...]
-# writes gpurun_out/prof_<tag>/{trace,fetch,write,sq}/ ; copy the summaries into profiles/.
+# kernel trace + stats in one run, PMC counters in runs of their own (never combined with traces);
+# writes gpurun_out/prof_<tag>/ ; bench_support/parse_prof.py summarises into profiles/.
 set -e
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -14,4 +15,4 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o fetch -- python3
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o write -- python3 $R/bench.py $ARGS > $OUT/write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM --output-format csv -d $OUT/sq -o sq -- python3 $R/bench.py $ARGS > $OUT/sq.log 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $OUT/tcc -o tcc -- python3 $R/bench.py $ARGS > $OUT/tcc.log 2>&1
-find $OUT -name "*.csv" | head -30
+grep -h '^{' $OUT/trace.log > $OUT/bench_under_trace.json || true
