@@ -75,6 +75,10 @@ const char *real_hip_strerror(int status);
 const char *real_hip_last_error(const real_hip_ctx *ctx);
 int  real_hip_abi_version(void);
 
+/* free / total HBM of the ctx's device in bytes: what getPhysicalMemory() * -f is to the
+ * reference's block sizing (matchUniqueImplementation.cpp:1208-1244)           */
+int real_hip_device_memory(real_hip_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes);
+
 /* ---- genome text: replaces what getText<sse4>() + RangeVector hand the
  * matcher (getText.hpp:31-55, AutoTextArray.hpp:63-109, RangeVector.hpp:46-58).
  * text2bit: 2 bits/base, base i at bits 63-2(i%32)-1.. of word i/32 (MSB

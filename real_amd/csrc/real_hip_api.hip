@@ -171,6 +171,16 @@ extern "C" void real_hip_destroy(real_hip_ctx *c)
     if (!(ctx)) return REAL_HIP_E_INVALID;              \
     RH_HIP((ctx), hipSetDevice((ctx)->device));
 
+extern "C" int real_hip_device_memory(real_hip_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes)
+{
+    RH_ENTER(ctx);
+    size_t f = 0, t = 0;
+    RH_HIP(ctx, hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return REAL_HIP_OK;
+}
+
 // ---------------------------------------------------------------------------
 // text
 // ---------------------------------------------------------------------------
