@@ -129,6 +129,8 @@ def main():
     ap.add_argument("--prefix-bits", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N>1 rehearsal on a 1-GPU box: every rank uses cuda:0 and the gather runs over gloo on host copies")
     args = ap.parse_args()
 
     import torch
@@ -140,9 +142,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.rehearse_on_one_gpu:
+        local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")     # RCCL over xGMI
+        dist.init_process_group("gloo" if args.rehearse_on_one_gpu else "nccl")     # nccl = RCCL over xGMI
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -179,7 +183,10 @@ def main():
         torch.cuda.current_stream().synchronize()
         m.match_unique(bases, qual, patl=args.patl, info=info, score=score, n_reads=n)
         if world > 1:                                          # the one collective: records to the root
-            gather_records(info, score, dst=0)
+            if args.rehearse_on_one_gpu:
+                gather_records(info.cpu(), score.cpu(), dst=0)
+            else:
+                gather_records(info, score, dst=0)
 
     for _ in range(args.warmup):
         step()
@@ -198,7 +205,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=("cpu" if args.rehearse_on_one_gpu else dev))
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 

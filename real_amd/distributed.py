@@ -40,12 +40,13 @@ def gather_records(info, score, dst: int = 0):
         out[:t.shape[0]] = t
         return out
 
-    gi: Optional[List] = [torch.empty(m, dtype=info.dtype, device=info.device) for _ in range(world)] if rank == dst else None
-    dist.gather(pad(info), gi, dst=dst)
-    gs = None
-    if score is not None:
-        gs = [torch.empty(m, dtype=score.dtype, device=score.device) for _ in range(world)] if rank == dst else None
-        dist.gather(pad(score), gs, dst=dst)
+    def gather(t):
+        out: Optional[List] = [torch.empty(m, dtype=t.dtype, device=t.device) for _ in range(world)] if rank == dst else None
+        dist.gather(pad(t), out, dst=dst)
+        return out
+
+    gi = gather(info)
+    gs = gather(score) if score is not None else None
     if rank != dst:
         return None, None
     info_all = torch.cat([g[:s] for g, s in zip(gi, sizes)])

@@ -1,0 +1,126 @@
+"""Size-independent properties of the HIP path at sizes the oracle cannot cover in full,
+plus oracle parity on a sample (BASELINE configs 2, 3, 5 shapes at reduced genome size)."""
+import numpy as np
+import pytest
+
+from real_amd import synth
+from real_amd.matcher import AllMatcher, RealOptions, UniqueMatcher, new_unique_info, unpack_info
+
+pytestmark = pytest.mark.gpu
+
+
+def _opts(seedl, k, scores):
+    return RealOptions(seedl=seedl, seedkmax=2, totalkmax=k, scores=bool(scores)).normalise()
+
+
+@pytest.mark.parametrize("seedl,patl,k", [(32, 100, 3), (64, 150, 5)])
+def test_unique_properties_mid_size(ora, seedl, patl, k):
+    g = synth.random_genome(8_000_000, seed=61, n_frag=4, n_runs=50, repeats=200)
+    b = synth.sample_reads(g, 150_000, patl, 0.02, seed=62, with_ids=False)
+    m = UniqueMatcher(_opts(seedl, k, 1))
+    m.set_text_symbols(0, g.sym, g.frag_start)
+    n, nxt = m.build_index_block()
+    assert not nxt and n > 7_900_000
+    info, score = m.match_unique(b.bases, b.qual, patl=patl)
+    st, fr, er, fi, po = unpack_info(info)
+    ok = (st == 1) | (st == 2)
+    # ground truth of the generator: a uniquely reported read sits where it was sampled, on its strand
+    assert ok.mean() > 0.75
+    assert np.array_equal(po[ok], b.true_pos[ok].astype(np.int64))
+    assert np.array_equal(st[ok] == 2, b.true_inv[ok])
+    assert np.all(er[ok] <= k)
+    # idempotence: folding the same block again changes nothing ("same place again" is a no-op)
+    info2, score2 = m.match_unique(b.bases, b.qual, patl=patl, info=info.copy(), score=score.copy())
+    assert np.array_equal(info2, info) and np.array_equal(score2.view(np.uint32), score.view(np.uint32))
+    # batch-split invariance: reads are independent
+    half = 75_000
+    ia, sa = m.match_unique(b.bases[:half * patl], b.qual[:half * patl], patl=patl)
+    ib, sb = m.match_unique(b.bases[half * patl:], b.qual[half * patl:], patl=patl)
+    assert np.array_equal(np.concatenate([ia, ib]), info)
+    assert np.array_equal(np.concatenate([sa, sb]).view(np.uint32), score.view(np.uint32))
+    # block composition: three index blocks folded in order == what the oracle gets the same way (sample)
+    info3, score3 = new_unique_info(b.n_reads, True)
+    first = 0
+    while True:
+        nb, nx = m.build_index_block(first, 3_000_000)
+        m.match_unique(b.bases, b.qual, patl=patl, info=info3, score=score3)
+        first += nb
+        if not nx:
+            break
+    sel = slice(0, 3000)
+    og = ora.Genome(g.sym, g.frag_start)
+    p = ora.make_params(seedl=seedl, seedkmax=2, totalkmax=k, scores=1)
+    oi = np.zeros(3000, np.uint64); os_ = np.full(3000, ora.NOSCORE_INIT, np.float32)
+    first = 0
+    while True:
+        ix = ora.Index(og, seedl, first, 3_000_000)
+        oi, os_, _ = ora.match_unique(og, ix, p, b.bases[:3000 * patl], b.qual[:3000 * patl], b.offsets[:3001], info=oi, score=os_)
+        first += ix.n
+        if not ix.have_next:
+            break
+    assert np.array_equal(info3[sel], oi) and np.array_equal(score3[sel].view(np.uint32), os_.view(np.uint32))
+    # and the one-block result on the same sample
+    ix = ora.Index(og, seedl)
+    oi1, os1, _ = ora.match_unique(og, ix, p, b.bases[:3000 * patl], b.qual[:3000 * patl], b.offsets[:3001])
+    assert np.array_equal(info[sel], oi1) and np.array_equal(score[sel].view(np.uint32), os1.view(np.uint32))
+    m.close()
+
+
+def test_match_all_properties_mid_size(ora):
+    g = synth.random_genome(4_000_000, seed=71, n_frag=3, repeats=400, repeat_len=150)
+    b = synth.sample_reads(g, 60_000, 100, 0.01, seed=72, with_ids=False)
+    a = AllMatcher(_opts(32, 2, 1))
+    a.set_text_symbols(0, g.sym, g.frag_start)
+    a.build_index_block()
+    hits, hoff = a.match_all(b.bases, b.qual, patl=100)
+    assert hoff[-1] == hits.shape[0] and np.all(np.diff(hoff.astype(np.int64)) >= 0)
+    # per read: sorted by (k, pos, score, inverted), no duplicates, every read index in its own segment
+    rd = np.repeat(np.arange(b.n_reads), np.diff(hoff.astype(np.int64)))
+    assert np.array_equal(hits["read"].astype(np.int64), rd)
+    key = np.stack([rd, hits["k"].astype(np.int64), hits["pos"].astype(np.int64)], axis=1)
+    assert np.all((np.diff(key, axis=0) != 0).any(axis=1) | (np.diff(hits["inverted"].astype(np.int64)) != 0))
+    order = np.lexsort((hits["inverted"], hits["score"], hits["pos"], hits["k"], rd))
+    assert np.array_equal(order, np.arange(hits.shape[0]))
+    assert np.all(hits["k"] <= 2)
+    # the sampled locus is among the hits of (nearly) every read; oracle parity on a sample
+    og = ora.Genome(g.sym, g.frag_start)
+    ix = ora.Index(og, 32)
+    p = ora.make_params(seedl=32, seedkmax=2, totalkmax=2, scores=1)
+    oh, ooff, _ = ora.match_all(og, ix, p, b.bases[:200_000], b.qual[:200_000], b.offsets[:2001])
+    assert np.array_equal(hoff[:2001], ooff)
+    n = int(ooff[-1])
+    for f in ("pos", "k", "inverted", "frag"):
+        assert np.array_equal(hits[f][:n].astype(np.int64), oh[f].astype(np.int64))
+    assert np.array_equal(hits["score"][:n].view(np.uint32), oh["score"].view(np.uint32))
+    a.close()
+
+
+def test_ragged_max_length_and_edge_reads(ora):
+    """reads of 32..256 bp in one batch (256 = REAL_HIP_MAX_PATL), reads at the very ends of fragments,
+    reads equal to the seed length, reads with N, reads shorter than the seed."""
+    g = synth.random_genome(300_000, seed=81, n_frag=6, n_runs=10)
+    parts = [synth.sample_reads(g, 300, L, 0.02, seed=82 + L, n_read_prob=0.001) for L in (32, 33, 64, 127, 128, 129, 200, 256)]
+    parts.append(synth.sample_reads(g, 50, 20, 0.0, seed=99))            # shorter than the seed: skipped
+    # reads ending exactly at a fragment end / starting at a fragment start
+    edge_b, edge_q, edge_o = [], [], [0]
+    for f in range(g.n_frag):
+        lo, hi = int(g.frag_start[f]), int(g.frag_start[f + 1])
+        for seg in (g.sym[lo:lo + 100], g.sym[hi - 100:hi], g.sym[hi - 50:hi + 50] if hi + 50 <= g.n else g.sym[lo:lo + 100]):
+            edge_b.append(seg); edge_q.append(np.full(100, 40, np.uint8)); edge_o.append(edge_o[-1] + 100)
+    parts.append(synth.ReadBatch(bases=np.concatenate(edge_b), qual=np.concatenate(edge_q), offsets=np.array(edge_o, np.uint64)))
+    b = synth.concat_batches(parts)
+    for scores in (1, 0):
+        m = UniqueMatcher(_opts(32, 4, scores))
+        m.set_text_symbols(0, g.sym, g.frag_start)
+        m.build_index_block()
+        info, score = m.match_unique(b.bases, b.qual, b.offsets)
+        og = ora.Genome(g.sym, g.frag_start)
+        ix = ora.Index(og, 32)
+        p = ora.make_params(seedl=32, seedkmax=2, totalkmax=4, scores=scores)
+        oi, os_, octr = ora.match_unique(og, ix, p, b.bases, b.qual, b.offsets)
+        assert np.array_equal(info, oi)
+        if scores:
+            assert np.array_equal(score.view(np.uint32), os_.view(np.uint32))
+        c = m.counters()
+        assert all(c[k] == octr[k] for k in ("reads", "lookups", "candidates", "seedpass", "hits"))
+        m.close()
