@@ -19,6 +19,7 @@ __device__ __forceinline__ uint64_t mix(uint64_t z)
 template <int MLP>
 __global__ void randread_kernel(const uint64_t *__restrict__ buf, uint64_t nwords, int rounds, uint64_t *out)
 {
+    const uint64_t t_start = __builtin_amdgcn_s_memtime();
     uint64_t s = mix(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull + 1);
     uint64_t acc = 0;
     for (int r = 0; r < rounds; ++r) {
@@ -33,6 +34,7 @@ __global__ void randread_kernel(const uint64_t *__restrict__ buf, uint64_t nword
         s = mix(s ^ acc); // next addresses depend on the data: a dependent chain like bucket -> entry -> text
     }
     if (acc == 0x1234567) out[0] = acc;
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[1] = __builtin_amdgcn_s_memtime() - t_start;
 }
 
 int main(int argc, char **argv)
@@ -44,9 +46,9 @@ int main(int argc, char **argv)
     uint64_t nwords = (uint64_t)(gb * (1ull << 30)) / 8;
     uint64_t *buf, *out;
     if (hipMalloc(&buf, nwords * 8) != hipSuccess) { printf("alloc failed\n"); return 1; }
-    hipMalloc(&out, 8);
+    hipMalloc(&out, 16);
     hipMemset(buf, 1, nwords * 8);
-    int blocks = 256 * wps; // 256 CUs x wps blocks of 256 threads = wps waves per SIMD
+    int blocks = argc > 5 ? atoi(argv[5]) : 256 * wps; // default: 256 CUs x wps blocks of 256 threads = wps waves per SIMD
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (int it = 0; it < 3; ++it) {
@@ -62,6 +64,10 @@ int main(int argc, char **argv)
         float ms = 0;
         hipEventElapsedTime(&ms, e0, e1);
         double acc = (double)blocks * 256 * rounds * mlp;
+        uint64_t hc[2] = {0, 0};
+        hipMemcpy(hc, out, 16, hipMemcpyDeviceToHost);
+        if (it == 2)
+            printf("[block 0 ran %.0f kcycles in %.3f ms => shader clock >= %.2f GHz] ", hc[1] / 1e3, ms, hc[1] / (ms * 1e6));
         if (it == 2)
             printf("gb=%.0f rounds=%d mlp=%d waves/simd=%d : %.3f ms, %.2f G reads/s, %.2f TB/s at 64 B/sector, round trip %.2f us\n", gb, rounds, mlp,
                    wps, ms, acc / ms / 1e6, acc * 64 / ms / 1e9, ms * 1e3 / rounds);

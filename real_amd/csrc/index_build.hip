@@ -88,12 +88,19 @@ uint32_t rh_choose_prefix_bits(const real_hip_ctx *ctx, uint64_t n_entries)
 {
     uint32_t l = ctx->prm.seedl;
     uint32_t pb = ctx->prm.prefix_bits;
-    if (!pb) { // auto: mean bucket of 2..4 entries (the first two entries of every bucket are prefetched
-               // together with one round trip), at most 2^30 buckets (4 GiB of starts per list)
+    if (!pb) {
         uint32_t lg = 0;
         while ((1ull << (lg + 1)) <= (n_entries ? n_entries : 1)) lg++;
-        pb = lg > 1 ? lg - 1 : 1;
-        if (pb < 8) pb = 8;
+        if (l <= 32 && lg >= 27) {
+            // large index, 32-bit signatures: prefix = all signature bits but two ("fine" tables: the bucket
+            // table also holds the sizes of the (at most four) key groups of a bucket, so a lookup lands on
+            // the reference's equal range without scanning); 8 B x 2^(l-2) per list
+            pb = l - 2;
+        } else {
+            // mean bucket of 2..4 entries (the first two entries of every bucket are prefetched together)
+            pb = lg > 1 ? lg - 1 : 1;
+            if (pb < 8) pb = 8;
+        }
         if (pb > 30) pb = 30;
     }
     if (pb > l) pb = l; // a signature has seedl bits (two segments of seedl/4 bases)
@@ -148,6 +155,25 @@ __global__ void entries_kernel(const K *__restrict__ sign, const uint32_t *__res
         for (uint64_t q = (uint64_t)p + 1; q <= nbuckets; ++q) bkt[q] = (uint32_t)n;
 }
 
+// fine bucket table: {start, sizes of the four key groups (one byte each)}.  255 means "255 or more":
+// the matcher then finds that group's bounds by binary search inside the bucket.
+__global__ void fine_table_kernel(const uint32_t *__restrict__ bkt, const uint2 *__restrict__ ent, uint64_t nbuckets,
+                                  uint32_t pbits, uint2 *__restrict__ out)
+{
+    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > nbuckets) return;
+    const uint32_t start = bkt[p];
+    uint32_t g[4] = {0, 0, 0, 0};
+    if (p < nbuckets) {
+        const uint32_t end = bkt[p + 1];
+        for (uint32_t j = start; j < end; ++j) {
+            const uint32_t k = (ent[j].x >> pbits) & 3;
+            if (g[k] < 255) g[k]++;
+        }
+    }
+    out[p] = make_uint2(start, g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24));
+}
+
 int rh_index_from_sorted(real_hip_ctx *ctx, int list, const void *d_sign, const uint32_t *d_pos, uint64_t n,
                          unsigned sig_bytes)
 {
@@ -157,10 +183,12 @@ int rh_index_from_sorted(real_hip_ctx *ctx, int list, const void *d_sign, const 
     const uint32_t nb = 1u << pb;
     int rc = rh_reserve(ctx, ctx->ent[list], (n ? n : 1) * sizeof(uint2));
     if (rc) return rc;
+    if (ctx->fine) rh_release(ctx->bkt[list]); // holds a uint2 table from the previous block
     rc = rh_reserve(ctx, ctx->bkt[list], ((size_t)nb + 1) * 4);
     if (rc) return rc;
     if (!n) {
-        RH_HIP(ctx, hipMemsetAsync(ctx->bkt[list].p, 0, ((size_t)nb + 1) * 4, ctx->stream));
+        if (ctx->fine && (rc = rh_reserve(ctx, ctx->bkt[list], ((size_t)nb + 1) * 8))) return rc;
+        RH_HIP(ctx, hipMemsetAsync(ctx->bkt[list].p, 0, ((size_t)nb + 1) * (ctx->fine ? 8 : 4), ctx->stream));
         return REAL_HIP_OK;
     }
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
@@ -172,6 +200,16 @@ int rh_index_from_sorted(real_hip_ctx *ctx, int list, const void *d_sign, const 
         hipLaunchKernelGGL(entries_kernel<uint64_t>, grid, block, 0, ctx->stream, (const uint64_t *)d_sign, d_pos, n, l, list, T,
                            pshift, fshift, fbits, pbits, nb, (uint2 *)ctx->ent[list].p, (uint32_t *)ctx->bkt[list].p);
     RH_HIP(ctx, hipGetLastError());
+    if (ctx->fine) {
+        DevBuf fine_tab;
+        if ((rc = rh_reserve(ctx, fine_tab, ((size_t)nb + 1) * sizeof(uint2)))) return rc;
+        hipLaunchKernelGGL(fine_table_kernel, dim3((unsigned)(((uint64_t)nb + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const uint32_t *)ctx->bkt[list].p, (const uint2 *)ctx->ent[list].p, (uint64_t)nb, pbits, (uint2 *)fine_tab.p);
+        RH_HIP(ctx, hipGetLastError());
+        RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        rh_release(ctx->bkt[list]);
+        ctx->bkt[list] = fine_tab;
+    }
     return REAL_HIP_OK;
 }
 
@@ -281,6 +319,7 @@ int rh_index_build_device(real_hip_ctx *ctx, uint64_t first_window, uint64_t max
     }
     ctx->n_entries = cnt;
     ctx->pb = rh_choose_prefix_bits(ctx, cnt);
+    ctx->fine = (l >= ctx->pb) && (l - ctx->pb) >= 1 && (l - ctx->pb) <= 2;
     for (int k = 0; k < 6; ++k) {
         rc = (l <= 32) ? sort_list<uint32_t>(ctx, k, d_wpos, cnt) : sort_list<uint64_t>(ctx, k, d_wpos, cnt);
         if (rc) return rc;

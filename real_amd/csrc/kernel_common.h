@@ -111,6 +111,21 @@ __device__ __forceinline__ unsigned long long wave_append_slot(unsigned long lon
     return (((unsigned long long)hi << 32) | lo) + rank;
 }
 
+// two consecutive u64 with one 16-byte request.  The address is only 8-byte aligned: global loads
+// need dword alignment on gfx950, and one request instead of two matters here -- the matcher is bound
+// by the number of memory requests it issues, not by bytes.
+struct __attribute__((packed, aligned(8))) U64x2 { uint64_t a, b; };
+__device__ __forceinline__ U64x2 load2(const uint64_t *__restrict__ p) { return *reinterpret_cast<const U64x2 *>(p); }
+
+// bits [o, o+nbits) of the 192-bit string t0|t1|t2 (o <= 127, 1 <= nbits <= 64), right aligned
+__device__ __forceinline__ uint64_t extract_bits(uint64_t t0, uint64_t t1, uint64_t t2, unsigned o, unsigned nbits)
+{
+    const uint64_t x = (o < 64) ? t0 : t1, y = (o < 64) ? t1 : t2;
+    o &= 63;
+    const uint64_t v = o ? ((x << o) | (y >> (64 - o))) : x;
+    return v >> (64 - nbits);
+}
+
 // reverse the order of the 2-bit symbols of a word
 __device__ __forceinline__ uint64_t rev2(uint64_t x)
 {

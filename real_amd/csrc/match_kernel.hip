@@ -57,14 +57,19 @@ __device__ __forceinline__ void process_candidate(const MatchArgs &a, LaneState<
                                                   uint32_t rpos, int la)
 {
     const uint64_t *__restrict__ T = a.t.text;
-    const uint32_t bb = a.b_bits, half = a.l >> 1;
+    const uint32_t bb = a.b_bits;
     const uint64_t mb = (bb >= 64) ? ~0ull : ((1ull << bb) - 1);
     // seed window of the genome at rpos, as the two halves (m0|m1), (m2|m3); per-segment mismatch
     // counts are a function of (strand, rpos) only and are memoised: the true locus is reached
     // through up to six lists in a row
     if (rpos != s.crpos) {
-        const uint64_t xhi = text_bits(T, rpos, half) ^ s.shi;
-        const uint64_t xlo = text_bits(T, (uint64_t)rpos + half, half) ^ s.slo;
+        // the seed window (2*l bits at bit offset 2*rpos) spans two words, three when l > 32
+        const uint64_t wi0 = rpos >> 5;
+        const U64x2 tt = load2(T + wi0);
+        const uint64_t t2 = (a.l > 32) ? T[wi0 + 2] : 0ull;
+        const unsigned sh0 = 2u * (rpos & 31);
+        const uint64_t xhi = extract_bits(tt.a, tt.b, t2, sh0, a.l) ^ s.shi;
+        const uint64_t xlo = extract_bits(tt.a, tt.b, t2, sh0 + a.l, a.l) ^ s.slo;
         const uint64_t dhi = ((xhi >> 1) | xhi) & M55, dlo = ((xlo >> 1) | xlo) & M55;
         s.ckk = __popcll(dhi >> bb) | (__popcll(dhi & mb) << 8) | (__popcll(dlo >> bb) << 16) | (__popcll(dlo & mb) << 24);
         s.crpos = rpos;
@@ -94,9 +99,13 @@ __device__ __forceinline__ void process_candidate(const MatchArgs &a, LaneState<
         uint64_t tw[W];
         unsigned total = 0;
         {
-            uint64_t t[W + 1];
+            uint64_t t[W + 2];
 #pragma unroll
-            for (int j = 0; j <= W; ++j) t[j] = ((uint32_t)j <= s.nw) ? T[wi + j] : 0ull; // all loads in flight together
+            for (int j = 0; j <= W; j += 2) { // 16-byte requests, all in flight together
+                U64x2 p2 = {0ull, 0ull};
+                if ((uint32_t)j <= s.nw) p2 = load2(T + wi + j);
+                t[j] = p2.a; t[j + 1] = p2.b;
+            }
 #pragma unroll
             for (int j = 0; j < W; ++j) {
                 uint64_t al = sh ? ((t[j] << sh) | (t[j + 1] >> (64 - sh))) : t[j];
@@ -184,7 +193,7 @@ __device__ __forceinline__ void process_candidate(const MatchArgs &a, LaneState<
 // drained (repeat-rich loci only): everything is recomputed from the seed halves and the cursors
 // parked in LDS, so that no scan state has to stay in registers across the drain (occupancy).
 // Returns true if the queue filled up (again).
-template <int W, bool SCORES, bool ALL, int LA0, int LA1, bool FIRST>
+template <int W, bool SCORES, bool ALL, bool FINE, int LA0, int LA1, bool FIRST>
 __device__ __forceinline__ bool scan_lists(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, uint32_t *q_pos, uint8_t *q_la,
                                            uint32_t *q_cur, uint32_t &donemask, uint32_t &qn)
 {
@@ -203,9 +212,11 @@ __device__ __forceinline__ bool scan_lists(const MatchArgs &a, LaneState<W, SCOR
         const uint64_t sa = (m[xa] << bb) | m[xc]; // s_a of list la, SignatureConstruction.hpp:62-67
         const uint32_t prefix = (uint32_t)(sa >> a.ix.pshift);
         fp[i] = (uint32_t)((sa >> a.ix.fshift) & ((a.ix.fbits >= 32) ? 0xffffffffull : ((1ull << a.ix.fbits) - 1)));
-        const uint32_t *__restrict__ bk = a.ix.bkt[la];
-        lo[i] = bk[prefix];
-        hi[i] = bk[prefix + 1];
+        {
+            const uint32_t *__restrict__ bk = a.ix.bkt[la];
+            lo[i] = bk[prefix];
+            hi[i] = bk[prefix + 1];
+        }
     }
     // 2. first two entries of every bucket: 2*NL independent loads
     uint2 e0[NL], e1[NL];
@@ -290,24 +301,122 @@ __device__ __forceinline__ bool scan_lists(const MatchArgs &a, LaneState<W, SCOR
     return again;
 }
 
-// lists [LA0, LA1) of one strand
+// Fine tables (32-bit signatures, large index): the bucket table entry {start, sizes of the four key
+// groups} of a prefix gives the reference's equal range of every list directly.  The lane enumerates the
+// equal ranges of all lists in list order -- the canonical candidate order -- four entries per round trip,
+// applies the partner filter and queues the survivors; a full queue is drained and refilled (the only
+// state across a drain is the enumeration offset).
 template <int W, bool SCORES, bool ALL, int LA0, int LA1>
-__device__ __forceinline__ void match_lists(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL,
-                                            uint32_t *q_pos, uint8_t *q_la, uint32_t *q_cur)
+__device__ __forceinline__ void match_lists_fine(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL,
+                                                 uint32_t *q_pos, uint8_t *q_la)
 {
-    uint32_t donemask = 0, qn = 0;
-    bool again = scan_lists<W, SCORES, ALL, LA0, LA1, true>(a, s, q_pos, q_la, q_cur, donemask, qn);
-    // 4. verify / score / fold in candidate order
-    for (uint32_t k = 0; k < qn; ++k)
-        process_candidate<W, SCORES, ALL>(a, s, sLL, q_pos[k * 256 + threadIdx.x], (int)q_la[k * 256 + threadIdx.x]);
-    while (again) {
-        again = scan_lists<W, SCORES, ALL, LA0, LA1, false>(a, s, q_pos, q_la, q_cur, donemask, qn);
+    const uint32_t bb = a.b_bits;
+    const uint64_t mb = (bb >= 64) ? ~0ull : ((1ull << bb) - 1);
+    const uint64_t m[4] = {s.shi >> bb, s.shi & mb, s.slo >> bb, s.slo & mb};
+    constexpr int NL = LA1 - LA0;
+    const uint32_t pbits = a.ix.pbits, pmask = (1u << pbits) - 1, G = 1u << a.ix.fbits;
+    uint32_t lo[NL], cum[NL], rp[NL], total = 0;
+    {
+        uint2 t[NL];
+        uint32_t f[NL], prefix[NL];
+        // 1. one 8-byte table entry per list, all in flight together
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int la = LA0 + i;
+            const int xa = (la < 3) ? 0 : (la < 5) ? 1 : 2, xc = (la == 0) ? 1 : (la == 1 || la == 3) ? 2 : 3;
+            const uint64_t sa = (m[xa] << bb) | m[xc]; // s_a of list la, SignatureConstruction.hpp:62-67
+            prefix[i] = (uint32_t)(sa >> a.ix.pshift);
+            f[i] = (uint32_t)sa & (G - 1);
+            const int lb = 5 - la; // partner signature s_b = signature of list 5-la
+            const int xb = (lb < 3) ? 0 : (lb < 5) ? 1 : 2, xd = (lb == 0) ? 1 : (lb == 1 || lb == 3) ? 2 : 3;
+            rp[i] = (uint32_t)(((m[xb] << bb) | m[xd]) >> (a.l - pbits));
+            t[i] = reinterpret_cast<const uint2 *>(a.ix.bkt[la])[prefix[i]];
+        }
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const uint32_t g0 = t[i].y & 255u, g1 = (t[i].y >> 8) & 255u, g2 = (t[i].y >> 16) & 255u, g3 = t[i].y >> 24;
+            const uint32_t fi = f[i];
+            uint32_t off = (fi > 0 ? g0 : 0u) + (fi > 1 ? g1 : 0u) + (fi > 2 ? g2 : 0u);
+            uint32_t sz = fi == 0 ? g0 : fi == 1 ? g1 : fi == 2 ? g2 : g3;
+            const bool sat = (g0 == 255u) || (fi > 0 && g1 == 255u) || (fi > 1 && g2 == 255u) || (fi > 2 && g3 == 255u);
+            uint32_t start = t[i].x + off;
+            if (sat) { // a group of 255 or more entries in front of / at the key: bounds by binary search
+                const uint2 *__restrict__ E = a.ix.ent[LA0 + i];
+                const uint32_t end = reinterpret_cast<const uint2 *>(a.ix.bkt[LA0 + i])[prefix[i] + 1].x;
+                uint32_t x = t[i].x, y = end;
+                while (x < y) { uint32_t mid = x + ((y - x) >> 1); if ((E[mid].x >> pbits) < fi) x = mid + 1; else y = mid; }
+                start = x; y = end;
+                while (x < y) { uint32_t mid = x + ((y - x) >> 1); if ((E[mid].x >> pbits) <= fi) x = mid + 1; else y = mid; }
+                sz = x - start;
+            }
+            lo[i] = start; cum[i] = total; total += sz;
+            s.cL++;
+        }
+    }
+    s.cC += total; s.cP += total;
+    // 2. enumerate, filter, queue, drain
+    for (uint32_t kb = 0; kb < total; kb += MQ) {
+        const uint32_t kend = min(total, kb + (uint32_t)MQ);
+        uint32_t qn = 0;
+        for (uint32_t k0 = kb; k0 < kend; k0 += 4) {
+            uint2 e[4];
+            uint32_t li[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t k = k0 + u;
+                if (k < kend) {
+                    uint32_t i = 0, base = cum[0], l0 = lo[0];
+                    const uint2 *E = a.ix.ent[LA0];
+#pragma unroll
+                    for (int j = 1; j < NL; ++j)
+                        if (k >= cum[j]) { i = j; base = cum[j]; l0 = lo[j]; E = a.ix.ent[LA0 + j]; }
+                    li[u] = i;
+                    e[u] = E[l0 + (k - base)];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (k0 + u < kend) {
+                    uint32_t r = rp[0];
+#pragma unroll
+                    for (int j = 1; j < NL; ++j) if (li[u] == (uint32_t)j) r = rp[j];
+                    // seed popcount filter (match.hpp:386) on the partner symbols the entry carries: more than
+                    // seedkmax known mismatches => rejected without touching the text (exact: the full count can
+                    // only be larger)
+                    const uint32_t x = (e[u].x & pmask) ^ r;
+                    if (__popc(((x >> 1) | x) & 0x55555555u) <= a.seedkmax) {
+                        q_pos[qn * 256 + threadIdx.x] = e[u].y;
+                        q_la[qn * 256 + threadIdx.x] = (uint8_t)(LA0 + li[u]);
+                        qn++;
+                    }
+                }
+            }
+        }
+        // 3. verify / score / fold in candidate order
         for (uint32_t k = 0; k < qn; ++k)
             process_candidate<W, SCORES, ALL>(a, s, sLL, q_pos[k * 256 + threadIdx.x], (int)q_la[k * 256 + threadIdx.x]);
     }
 }
 
-template <int W, bool SCORES, bool ALL>
+// lists [LA0, LA1) of one strand
+template <int W, bool SCORES, bool ALL, bool FINE, int LA0, int LA1>
+__device__ __forceinline__ void match_lists(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL,
+                                            uint32_t *q_pos, uint8_t *q_la, uint32_t *q_cur)
+{
+    if (FINE) { match_lists_fine<W, SCORES, ALL, LA0, LA1>(a, s, sLL, q_pos, q_la); return; }
+    uint32_t donemask = 0, qn = 0;
+    bool again = scan_lists<W, SCORES, ALL, FINE, LA0, LA1, true>(a, s, q_pos, q_la, q_cur, donemask, qn);
+    // 4. verify / score / fold in candidate order
+    for (uint32_t k = 0; k < qn; ++k)
+        process_candidate<W, SCORES, ALL>(a, s, sLL, q_pos[k * 256 + threadIdx.x], (int)q_la[k * 256 + threadIdx.x]);
+    while (again) {
+        again = scan_lists<W, SCORES, ALL, FINE, LA0, LA1, false>(a, s, q_pos, q_la, q_cur, donemask, qn);
+        for (uint32_t k = 0; k < qn; ++k)
+            process_candidate<W, SCORES, ALL>(a, s, sLL, q_pos[k * 256 + threadIdx.x], (int)q_la[k * 256 + threadIdx.x]);
+    }
+}
+
+template <int W, bool SCORES, bool ALL, bool FINE>
 __global__ __launch_bounds__(256) void match_kernel(MatchArgs a)
 {
     __shared__ double sLL[SCORES ? 1024 : 1];
@@ -338,9 +447,14 @@ __global__ __launch_bounds__(256) void match_kernel(MatchArgs a)
         for (int inv = 0; inv < 2; ++inv) {
             const uint64_t *wp = a.b.words + r * (2 * W) + inv * W;
 #pragma unroll
-            for (int j = 0; j < W; ++j) s.O[j] = wp[j];
-            s.shi = a.b.seeds[r * 4 + inv * 2];
-            s.slo = a.b.seeds[r * 4 + inv * 2 + 1];
+            for (int j = 0; j < W; j += 2) {
+                if (j + 1 < W) { const U64x2 p2 = load2(wp + j); s.O[j] = p2.a; s.O[j + 1] = p2.b; }
+                else s.O[j] = wp[j];
+            }
+            {
+                const U64x2 sd = load2(a.b.seeds + r * 4 + inv * 2);
+                s.shi = sd.a; s.slo = sd.b;
+            }
             s.inv = inv;
             s.so = inv ? (patl - a.l) : 0u; // RestMatch::getMatchOffset, RestMatch.hpp:84-89
             s.cpos = 0xffffffffu; s.ck = 0; s.cfrag = 0; s.cscore = 1.0f; s.cok = false;
@@ -348,12 +462,12 @@ __global__ __launch_bounds__(256) void match_kernel(MatchArgs a)
             if (!ALL && !SCORES) {
                 // uni0s / uni0r early-out (matchUniqueImplementation.cpp:434-436, 470-472): lists 1..5 of a
                 // strand are skipped when list 0 left the record in this strand's state with 0 errors
-                match_lists<W, SCORES, ALL, 0, 1>(a, s, sLL, q_pos, q_la, q_cur);
+                match_lists<W, SCORES, ALL, FINE, 0, 1>(a, s, sLL, q_pos, q_la, q_cur);
                 const unsigned st = (unsigned)(s.info >> ST_SHIFT), er = (unsigned)(s.info >> ER_SHIFT) & 15;
                 if (!(st == (unsigned)(inv ? ST_REVERSE : ST_STRAIGHT) && er == 0))
-                    match_lists<W, SCORES, ALL, 1, 6>(a, s, sLL, q_pos, q_la, q_cur);
+                    match_lists<W, SCORES, ALL, FINE, 1, 6>(a, s, sLL, q_pos, q_la, q_cur);
             } else {
-                match_lists<W, SCORES, ALL, 0, 6>(a, s, sLL, q_pos, q_la, q_cur);
+                match_lists<W, SCORES, ALL, FINE, 0, 6>(a, s, sLL, q_pos, q_la, q_cur);
             }
         }
         if (!ALL) {
@@ -375,18 +489,24 @@ __global__ __launch_bounds__(256) void match_kernel(MatchArgs a)
 // ---------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------
-template <int W>
-static void launch_match_w(real_hip_ctx *ctx, const MatchArgs &a, bool all)
+template <int W, bool FINE>
+static void launch_match_wf(real_hip_ctx *ctx, const MatchArgs &a, bool all)
 {
     dim3 grid((unsigned)((a.b.n_reads + 255) / 256)), block(256);
     const bool sc = ctx->prm.scores != 0;
     if (all) {
-        if (sc) hipLaunchKernelGGL((match_kernel<W, true, true>), grid, block, 0, ctx->stream, a);
-        else    hipLaunchKernelGGL((match_kernel<W, false, true>), grid, block, 0, ctx->stream, a);
+        if (sc) hipLaunchKernelGGL((match_kernel<W, true, true, FINE>), grid, block, 0, ctx->stream, a);
+        else    hipLaunchKernelGGL((match_kernel<W, false, true, FINE>), grid, block, 0, ctx->stream, a);
     } else {
-        if (sc) hipLaunchKernelGGL((match_kernel<W, true, false>), grid, block, 0, ctx->stream, a);
-        else    hipLaunchKernelGGL((match_kernel<W, false, false>), grid, block, 0, ctx->stream, a);
+        if (sc) hipLaunchKernelGGL((match_kernel<W, true, false, FINE>), grid, block, 0, ctx->stream, a);
+        else    hipLaunchKernelGGL((match_kernel<W, false, false, FINE>), grid, block, 0, ctx->stream, a);
     }
+}
+template <int W>
+static void launch_match_w(real_hip_ctx *ctx, const MatchArgs &a, bool all)
+{
+    if (a.ix.fine) launch_match_wf<W, true>(ctx, a, all);
+    else launch_match_wf<W, false>(ctx, a, all);
 }
 
 int rh_launch_match(real_hip_ctx *ctx, const MatchArgs &a, bool all)

@@ -265,6 +265,7 @@ extern "C" int real_hip_set_index_block(real_hip_ctx *ctx, uint64_t n, const voi
     ctx->have_index = false;
     ctx->n_entries = n;
     ctx->pb = rh_choose_prefix_bits(ctx, n);
+    ctx->fine = (ctx->prm.seedl - ctx->pb) <= 2 && ctx->prm.seedl >= ctx->pb && (ctx->prm.seedl - ctx->pb) >= 1;
     RhTimer tm(ctx, REAL_HIP_K_INDEX);
     int rc;
     if ((rc = rh_reserve(ctx, ctx->keys_a, (n ? n : 1) * sb))) return rc;
@@ -307,7 +308,11 @@ extern "C" int real_hip_index_download(real_hip_ctx *ctx, int list, uint32_t *en
     if (list < 0 || list > 5) return rh_fail(ctx, REAL_HIP_E_INVALID, "list", hipSuccess);
     const uint64_t n = ctx->n_entries;
     if (n && entries) RH_HIP(ctx, hipMemcpy(entries, ctx->ent[list].p, n * sizeof(uint2), hipMemcpyDeviceToHost));
-    if (bucket) RH_HIP(ctx, hipMemcpy(bucket, ctx->bkt[list].p, (((size_t)1 << ctx->pb) + 1) * 4, hipMemcpyDeviceToHost));
+    if (bucket) {
+        const size_t nbk = ((size_t)1 << ctx->pb) + 1;
+        if (ctx->fine) RH_HIP(ctx, hipMemcpy2D(bucket, 4, ctx->bkt[list].p, 8, 4, nbk, hipMemcpyDeviceToHost)); // the .x of every uint2
+        else RH_HIP(ctx, hipMemcpy(bucket, ctx->bkt[list].p, nbk * 4, hipMemcpyDeviceToHost));
+    }
     return REAL_HIP_OK;
 }
 
@@ -396,6 +401,7 @@ static void fill_args(real_hip_ctx *ctx, const Staged &s, uint64_t n, MatchArgs 
     for (int k = 0; k < 6; ++k) { a.ix.ent[k] = (const uint2 *)ctx->ent[k].p; a.ix.bkt[k] = (const uint32_t *)ctx->bkt[k].p; }
     a.ix.n = ctx->n_entries; a.ix.pb = pb;
     rh_index_geometry(l, pb, &a.ix.pshift, &a.ix.fshift, &a.ix.fbits, &a.ix.pbits);
+    a.ix.fine = ctx->fine ? 1u : 0u;
     a.b.words = (const uint64_t *)ctx->words.p; a.b.seeds = (const uint64_t *)ctx->seeds.p;
     a.b.qrows = (const uint8_t *)ctx->qrows.p; a.b.patl = (const uint32_t *)ctx->patl.p;
     a.b.n_reads = n; a.b.W = s.W; a.b.QS = s.QS;

@@ -29,13 +29,14 @@ struct DevText {
 // reference's equal range appear in the reference's order.
 struct DevIndex {
     const uint2    *ent[6];
-    const uint32_t *bkt[6]; // 2^pb + 1 bucket starts
+    const uint32_t *bkt[6]; // 2^pb + 1 bucket starts (u32), or in fine mode uint2 {start, key-group sizes}
     uint64_t n;
     uint32_t pb;     // prefix bits
     uint32_t pshift; // sig_bits - pb: prefix = sign >> pshift
     uint32_t fshift; // entry.x = [fbits of (sign >> fshift)] [pbits of the partner signature's top bits]
     uint32_t fbits;  // signature bits kept in the entry (all sig_bits - pb of them when that is <= 30)
     uint32_t pbits;  // partner-signature bits kept in the entry (even; 0 when the signature needs all 32)
+    uint32_t fine;   // 1: fbits <= 2 and the bucket table carries the sizes of the key groups of every bucket
 };
 
 // entry geometry shared by the index build and the matcher
@@ -101,6 +102,7 @@ struct real_hip_ctx {
     DevBuf ent[6], bkt[6];
     uint64_t n_entries = 0;
     uint32_t pb = 0;
+    bool fine = false; // bucket tables are uint2 {start, group sizes} (signature bits below the prefix <= 2)
     bool have_index = false;
 
     // tables / counters

@@ -126,8 +126,11 @@ def test_match_all_golden_inputs(ora, path):
     (32, 100, 3, 1, 4),          # 16 buckets: every bucket is large -> in-bucket binary search path
     (64, 150, 5, 1, 12),         # signature wider than prefix+32: fingerprint + text confirmation path
     (16, 50, 4, 1, 0), (20, 255, 15, 1, 0), (4, 20, 2, 0, 0), (32, 32, 2, 1, 0),
+    # fine bucket tables (prefix = all signature bits but two / one): equal ranges straight from the table
+    (16, 50, 4, 1, 14), (16, 50, 4, 0, 14), (12, 40, 4, 1, 11), (8, 30, 3, 1, 6), (32, 100, 3, 1, 30),
 ])
 def test_match_unique_random(ora, seedl, patl, k, scores, pb):
+    # (short seeds on a 3 kbp genome: equal ranges of hundreds of entries -> queue refills, 255-saturated groups)
     g = synth.random_genome(200_000 if seedl >= 16 else 3000, seed=100 + seedl + patl, n_frag=5, n_runs=20, repeats=30)
     b = synth.sample_reads(g, 4000 if seedl >= 16 else 300, patl, 0.02, seed=200 + patl, n_read_prob=0.0005)
     seedk = min(2, k)
@@ -141,6 +144,26 @@ def test_match_unique_random(ora, seedl, patl, k, scores, pb):
     c = m.counters()
     for kk in ("reads", "lookups", "candidates", "seedpass", "hits"):
         assert c[kk] == octr[kk], (kk, c[kk], octr[kk])
+    m.close()
+
+
+def test_match_all_fine_tables(ora):
+    g = synth.random_genome(100_000, seed=91, n_frag=3, n_runs=5, repeats=40)
+    b = synth.sample_reads(g, 3000, 60, 0.02, seed=92)
+    og = ora.Genome(g.sym, g.frag_start)
+    ix = ora.Index(og, 16)
+    p = ora.make_params(seedl=16, seedkmax=2, totalkmax=3, scores=1)
+    ohits, ooff, octr = ora.match_all(og, ix, p, b.bases, b.qual, b.offsets)
+    m = AllMatcher(_opts(16, 2, 3, 1), prefix_bits=14)
+    m.set_text_symbols(0, g.sym, g.frag_start)
+    m.build_index_block()
+    hits, hoff = m.match_all(b.bases, b.qual, b.offsets)
+    assert np.array_equal(hoff, ooff)
+    for x, y in zip(_hits_tuple(hits), _hits_tuple(ohits)):
+        assert np.array_equal(x, y)
+    c = m.counters()
+    for k in ("reads", "lookups", "candidates", "seedpass", "hits"):
+        assert c[k] == octr[k]
     m.close()
 
 
