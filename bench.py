@@ -129,6 +129,10 @@ def main():
     ap.add_argument("--prefix-bits", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--mode", choices=["unique", "all"], default="unique",
+                    help="unique = BASELINE configs[1] (default, what the driver runs); all = configs[2] (matchAll, manual runs)")
+    ap.add_argument("--host-buffers", action="store_true",
+                    help="hand the batch over as host buffers (PCIe-inclusive rate for DESIGN.md; never the headline value)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N>1 rehearsal on a 1-GPU box: every rank uses cuda:0 and the gather runs over gloo on host copies")
     args = ap.parse_args()
@@ -136,7 +140,7 @@ def main():
     import torch
     import torch.distributed as dist
     from real_amd import lib as rlib
-    from real_amd.matcher import RealOptions, UniqueMatcher
+    from real_amd.matcher import AllMatcher, RealOptions, UniqueMatcher
     from real_amd.distributed import gather_records
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -159,7 +163,7 @@ def main():
     t_setup = time.time()
     sym = gen_genome(torch, G, 3, dev)                       # i.i.d. uniform ACGT, one fragment, seed 3
     frag = np.array([0, G], dtype=np.uint64)
-    m = UniqueMatcher(opts, device=local, prefix_bits=args.prefix_bits)
+    m = (UniqueMatcher if args.mode == "unique" else AllMatcher)(opts, device=local, prefix_bits=args.prefix_bits)
     torch.cuda.synchronize()
     log("genome generated")
     m.set_text_symbols(0, sym, frag)
@@ -177,6 +181,49 @@ def main():
     info = torch.zeros(n, dtype=torch.int64, device=dev)
     score = torch.empty(n, dtype=torch.float32, device=dev)
     t_setup = time.time() - t_setup
+
+    if args.mode == "all" or args.host_buffers:
+        # manual side measurements (matchAll; host buffers): their own simple loop and JSON line
+        import ctypes as C
+        from real_amd.lib import HIT_DTYPE, RealHipBatch
+        hb = bases.cpu().numpy() if args.host_buffers else None
+        hq = qual.cpu().numpy() if args.host_buffers else None
+        cap = 4 * n
+        hits_dev = torch.empty(cap * 16, dtype=torch.uint8, device=dev) if not args.host_buffers else None
+        hoff_dev = torch.empty(n + 1, dtype=torch.int64, device=dev) if not args.host_buffers else None
+        nh = 0
+
+        def side_step():
+            nonlocal nh
+            if args.mode == "unique":
+                hi, hs = m.match_unique(hb, hq, patl=args.patl, n_reads=n)
+                return
+            if args.host_buffers:
+                h, o = m.match_all(hb, hq, patl=args.patl, n_reads=n, cap=cap)
+                nh = h.shape[0]
+                return
+            b = m._batch(bases, qual, None, args.patl, n)
+            nout = C.c_uint64(0)
+            rc = m._L.real_hip_match_all(m._h, C.byref(b), hits_dev.data_ptr(), cap, C.byref(nout), hoff_dev.data_ptr())
+            m._check(rc)
+            nh = int(nout.value)
+
+        for _ in range(args.warmup):
+            side_step()
+        for kk in range(5):
+            m.kernel_time(kk, reset=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            side_step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(json.dumps({"side_measurement": True, "mode": args.mode, "host_buffers": bool(args.host_buffers),
+                          "reads_per_s": n * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "hits_per_step": nh,
+                          "genome_bp": G, "reads": n, "read_len": args.patl, "seedl": args.seedl, "totalk": args.totalk,
+                          "kernel_ms": {nm: m.kernel_time(i)[0] / max(m.kernel_time(i)[1], 1)
+                                        for i, nm in enumerate(["pack", "match_unique", "match_all", "all_sort", "index"])}}), flush=True)
+        return
 
     def step():
         info.zero_(); score.fill_(-3.4028234663852886e38)     # uniqueinfo(numpat): state NoMatch, score -FLT_MAX
@@ -229,7 +276,8 @@ def main():
             try:
                 tj = json.load(open(tfile))
                 key = "match_unique_%dMbp_%dreads" % (int(args.genome_mbp), n)
-                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+                if (args.patl, args.seedl, args.totalk, args.scores) == (100, 32, 3, 1):     # the profiled configuration only
+                    traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -247,7 +295,7 @@ def main():
                        "uniquely_aligned_frac_rank0": aligned / n, "index_build_s": t_index, "setup_s": t_setup},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "match_kernel<4,scores,unique>", "avg_launch_ms": avg_ms, "launches": match_n,
+                         "kernel": "match_kernel<W=%d,scores=%d,unique,fine=%d>" % ((args.patl + 31) // 32, args.scores, int(args.seedl - m.prefix_bits <= 2)), "avg_launch_ms": avg_ms, "launches": match_n,
                          "algorithmic_bytes_per_read": a_total / max(ctr["reads"], 1),
                          "pack_kernel_avg_ms": pack_ms / max(pack_n, 1),
                          "work_per_read": {k: ctr[k] / max(ctr["reads"], 1) for k in ("lookups", "probes", "candidates", "seedpass", "hits", "verified")}},

@@ -17,11 +17,12 @@ __device__ __forceinline__ uint64_t mix(uint64_t z)
 }
 
 template <int MLP>
-__global__ void randread_kernel(const uint64_t *__restrict__ buf, uint64_t nwords, int rounds, uint64_t *out)
+__global__ void randread_kernel(const uint64_t *__restrict__ buf, uint64_t nwords, int rounds, uint64_t *out, int active)
 {
     const uint64_t t_start = __builtin_amdgcn_s_memtime();
     uint64_t s = mix(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull + 1);
     uint64_t acc = 0;
+    if ((int)(threadIdx.x & 63) >= active) return; // only `active` lanes of every wave issue loads
     for (int r = 0; r < rounds; ++r) {
         uint64_t v[MLP];
 #pragma unroll
@@ -43,6 +44,7 @@ int main(int argc, char **argv)
     int rounds = argc > 2 ? atoi(argv[2]) : 64;
     int mlp = argc > 3 ? atoi(argv[3]) : 1;
     int wps = argc > 4 ? atoi(argv[4]) : 8;
+    int active = argc > 6 ? atoi(argv[6]) : 64;
     uint64_t nwords = (uint64_t)(gb * (1ull << 30)) / 8;
     uint64_t *buf, *out;
     if (hipMalloc(&buf, nwords * 8) != hipSuccess) { printf("alloc failed\n"); return 1; }
@@ -54,22 +56,22 @@ int main(int argc, char **argv)
     for (int it = 0; it < 3; ++it) {
         hipEventRecord(e0);
         switch (mlp) {
-        case 1: hipLaunchKernelGGL(randread_kernel<1>, dim3(blocks), dim3(256), 0, 0, buf, nwords, rounds, out); break;
-        case 2: hipLaunchKernelGGL(randread_kernel<2>, dim3(blocks), dim3(256), 0, 0, buf, nwords, rounds, out); break;
-        case 4: hipLaunchKernelGGL(randread_kernel<4>, dim3(blocks), dim3(256), 0, 0, buf, nwords, rounds, out); break;
-        default: hipLaunchKernelGGL(randread_kernel<8>, dim3(blocks), dim3(256), 0, 0, buf, nwords, rounds, out); break;
+        case 1: hipLaunchKernelGGL(randread_kernel<1>, dim3(blocks), dim3(256), 0, 0, buf, nwords, rounds, out, active); break;
+        case 2: hipLaunchKernelGGL(randread_kernel<2>, dim3(blocks), dim3(256), 0, 0, buf, nwords, rounds, out, active); break;
+        case 4: hipLaunchKernelGGL(randread_kernel<4>, dim3(blocks), dim3(256), 0, 0, buf, nwords, rounds, out, active); break;
+        default: hipLaunchKernelGGL(randread_kernel<8>, dim3(blocks), dim3(256), 0, 0, buf, nwords, rounds, out, active); break;
         }
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms = 0;
         hipEventElapsedTime(&ms, e0, e1);
-        double acc = (double)blocks * 256 * rounds * mlp;
+        double acc = (double)blocks * 4 * active * rounds * mlp;
         uint64_t hc[2] = {0, 0};
         hipMemcpy(hc, out, 16, hipMemcpyDeviceToHost);
         if (it == 2)
             printf("[block 0 ran %.0f kcycles in %.3f ms => shader clock >= %.2f GHz] ", hc[1] / 1e3, ms, hc[1] / (ms * 1e6));
         if (it == 2)
-            printf("gb=%.0f rounds=%d mlp=%d waves/simd=%d : %.3f ms, %.2f G reads/s, %.2f TB/s at 64 B/sector, round trip %.2f us\n", gb, rounds, mlp,
+            printf("active=%d gb=%.0f rounds=%d mlp=%d waves/simd=%d : %.3f ms, %.2f G reads/s, %.2f TB/s at 64 B/sector, round trip %.2f us\n", active, gb, rounds, mlp,
                    wps, ms, acc / ms / 1e6, acc * 64 / ms / 1e9, ms * 1e3 / rounds);
     }
     return 0;
