@@ -25,6 +25,7 @@
 // are what keep the number of sequential round trips per wave small.
 #include "kernel_common.h"
 
+#define EB 8  // index entries a lane requests per round trip while enumerating equal ranges
 #define MQ 16 // candidate queue slots per lane (LDS); a full queue is drained and refilled
 
 template <int W, bool SCORES, bool ALL>
@@ -358,11 +359,11 @@ __device__ __forceinline__ void match_lists_fine(const MatchArgs &a, LaneState<W
     for (uint32_t kb = 0; kb < total; kb += MQ) {
         const uint32_t kend = min(total, kb + (uint32_t)MQ);
         uint32_t qn = 0;
-        for (uint32_t k0 = kb; k0 < kend; k0 += 4) {
-            uint2 e[4];
-            uint32_t li[4];
+        for (uint32_t k0 = kb; k0 < kend; k0 += EB) {
+            uint2 e[EB];
+            uint32_t li[EB];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < EB; ++u) {
                 const uint32_t k = k0 + u;
                 if (k < kend) {
                     uint32_t i = 0, base = cum[0], l0 = lo[0];
@@ -375,7 +376,7 @@ __device__ __forceinline__ void match_lists_fine(const MatchArgs &a, LaneState<W
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < EB; ++u) {
                 if (k0 + u < kend) {
                     uint32_t r = rp[0];
 #pragma unroll
