@@ -53,7 +53,7 @@ __global__ void count_wild_kernel(const uint64_t *__restrict__ wild, uint64_t nw
 int rh_pack_text(real_hip_ctx *ctx, const uint8_t *d_sym, uint64_t n)
 {
     uint64_t nw = (n + 63) / 64;
-    unsigned long long *d_cnt = (unsigned long long *)ctx->counters.p + 8; // scratch slot
+    unsigned long long *d_cnt = (unsigned long long *)ctx->counters.p + (size_t)RH_CSTRIPES * 16; // scratch slot behind the stripes
     RH_HIP(ctx, hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
     if (nw)
         hipLaunchKernelGGL(pack_text_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, ctx->stream, d_sym, n,
@@ -69,7 +69,7 @@ int rh_pack_text(real_hip_ctx *ctx, const uint8_t *d_sym, uint64_t n)
 int rh_count_wild(real_hip_ctx *ctx, uint64_t n)
 {
     uint64_t nw = (n + 63) / 64;
-    unsigned long long *d_cnt = (unsigned long long *)ctx->counters.p + 8;
+    unsigned long long *d_cnt = (unsigned long long *)ctx->counters.p + (size_t)RH_CSTRIPES * 16;
     RH_HIP(ctx, hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
     if (nw)
         hipLaunchKernelGGL(count_wild_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, ctx->stream,

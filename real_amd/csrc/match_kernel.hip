@@ -483,7 +483,8 @@ __global__ __launch_bounds__(256) void match_kernel(MatchArgs a)
     for (int k = 0; k < 7; ++k) {
         unsigned v = c[k];
         for (int d = 32; d; d >>= 1) v += __shfl_xor((int)v, d);
-        if ((threadIdx.x & 63) == 0 && v) atomicAdd(a.counters + k, (unsigned long long)v);
+        if ((threadIdx.x & 63) == 0 && v)
+            atomicAdd(a.counters + (size_t)((blockIdx.x * 4u + (threadIdx.x >> 6)) & (RH_CSTRIPES - 1)) * 16 + k, (unsigned long long)v);
     }
 }
 

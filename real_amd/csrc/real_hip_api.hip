@@ -142,9 +142,9 @@ extern "C" int real_hip_create(real_hip_ctx **out, const real_hip_params *p)
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = REAL_HIP_E_DEVICE; break; }
         if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { rc = REAL_HIP_E_DEVICE; break; }
         if ((rc = rh_reserve(c, c->LL, 1024 * sizeof(double)))) break;
-        if ((rc = rh_reserve(c, c->counters, 16 * sizeof(uint64_t)))) break;
+        if ((rc = rh_reserve(c, c->counters, (size_t)(RH_CSTRIPES + 1) * 16 * sizeof(uint64_t)))) break;
         if (hipMemcpy(c->LL.p, p->LL, 1024 * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { rc = REAL_HIP_E_DEVICE; break; }
-        if (hipMemset(c->counters.p, 0, 16 * sizeof(uint64_t)) != hipSuccess) { rc = REAL_HIP_E_DEVICE; break; }
+        if (hipMemset(c->counters.p, 0, (size_t)(RH_CSTRIPES + 1) * 16 * sizeof(uint64_t)) != hipSuccess) { rc = REAL_HIP_E_DEVICE; break; }
     } while (0);
     if (rc) { real_hip_destroy(c); return rc; }
     *out = c;
@@ -495,10 +495,13 @@ extern "C" int real_hip_match_all(real_hip_ctx *ctx, const real_hip_batch *b, re
 extern "C" int real_hip_counters_get(real_hip_ctx *ctx, real_hip_counters *out, int reset)
 {
     RH_ENTER(ctx);
-    uint64_t h[8];
-    RH_HIP(ctx, hipMemcpyAsync(h, ctx->counters.p, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
-    if (reset) RH_HIP(ctx, hipMemsetAsync(ctx->counters.p, 0, sizeof h, ctx->stream));
+    std::vector<uint64_t> all((size_t)RH_CSTRIPES * 16);
+    RH_HIP(ctx, hipMemcpyAsync(all.data(), ctx->counters.p, all.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (reset) RH_HIP(ctx, hipMemsetAsync(ctx->counters.p, 0, all.size() * 8, ctx->stream));
     RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (size_t st = 0; st < RH_CSTRIPES; ++st)
+        for (int k = 0; k < 8; ++k) h[k] += all[st * 16 + k];
     if (out) {
         out->reads = h[0]; out->lookups = h[1]; out->probes = h[2]; out->candidates = h[3];
         out->seedpass = h[4]; out->hits = h[5]; out->verified = h[6]; out->reserved = 0;

@@ -10,6 +10,10 @@
 #include "real_hip.h"
 
 #define RH_MAXW 8 /* 64-bit words per oriented read: REAL_HIP_MAX_PATL / 32 */
+// Work counters are striped over this many 128-byte lines: every wave ends with a handful of atomics,
+// and 781 k waves hammering ONE line serialise at the L2 channel that owns it (measured: the whole
+// kernel then runs at the atomic rate, independent of the genome size).
+#define RH_CSTRIPES 1024
 
 // ---- device-side views ------------------------------------------------------
 struct DevText {
@@ -70,7 +74,7 @@ struct MatchArgs {
     const double *LL;      // device copy of the 4x4x64 table
     uint64_t *info;        // in/out records
     float    *score;       // in/out scores (scores mode)
-    unsigned long long *counters; // 8 x u64
+    unsigned long long *counters; // RH_CSTRIPES stripes x 16 u64 (one 128-B line per stripe), summed on the host
     // matchAll
     uint4 *raw;            // raw hit records
     unsigned long long *raw_count;
