@@ -514,7 +514,7 @@ static void launch_match_w(real_hip_ctx *ctx, const MatchArgs &a, bool all)
 int rh_launch_match(real_hip_ctx *ctx, const MatchArgs &a, bool all)
 {
     if (!a.b.n_reads) return REAL_HIP_OK;
-    RhTimer tm(ctx, all ? REAL_HIP_K_MATCH_ALL : REAL_HIP_K_MATCH_UNIQUE);
+    rh_time_begin(ctx, ctx->stream, all ? REAL_HIP_K_MATCH_ALL : REAL_HIP_K_MATCH_UNIQUE);
     switch (a.b.W) {
     case 1: launch_match_w<1>(ctx, a, all); break;
     case 2: launch_match_w<2>(ctx, a, all); break;
@@ -526,6 +526,7 @@ int rh_launch_match(real_hip_ctx *ctx, const MatchArgs &a, bool all)
     case 8: launch_match_w<8>(ctx, a, all); break;
     default: return rh_fail(ctx, REAL_HIP_E_UNSUPPORTED, "read longer than REAL_HIP_MAX_PATL", hipSuccess);
     }
+    rh_time_end(ctx, ctx->stream);
     RH_HIP(ctx, hipGetLastError());
     return REAL_HIP_OK;
 }

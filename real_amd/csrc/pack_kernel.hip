@@ -147,34 +147,34 @@ __global__ void max_patl_kernel(const uint64_t *__restrict__ off, uint64_t n, ui
 // launchers
 // ---------------------------------------------------------------------------
 template <int W>
-static void launch_pack_w(real_hip_ctx *ctx, const uint8_t *d_bases, const uint8_t *d_qual, const uint64_t *d_off,
-                          uint32_t upatl, uint64_t n, uint32_t QS)
+static void launch_pack_w(real_hip_ctx *ctx, hipStream_t st, const uint8_t *d_bases, const uint8_t *d_qual, const uint64_t *d_off,
+                          uint32_t upatl, uint64_t n, uint32_t QS, const PackOut &out)
 {
     dim3 grid((unsigned)((n + PACK_RB - 1) / PACK_RB)), block(PACK_RB);
     const size_t lds_bytes = (size_t)PACK_RB * 32 * W + 32; // the block's contiguous byte range + alignment skew
     // above the 64 KiB default only for W = 8; gfx950 has 160 KiB of LDS per CU
     (void)hipFuncSetAttribute((const void *)pack_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL(pack_kernel<W>, grid, block, lds_bytes, ctx->stream, d_bases, d_qual, d_off, upatl, n, ctx->prm.seedl, QS,
-                       (int)(ctx->prm.scores != 0), (uint64_t *)ctx->words.p, (uint64_t *)ctx->seeds.p,
-                       (uint8_t *)ctx->qrows.p, (uint32_t *)ctx->patl.p);
+    hipLaunchKernelGGL(pack_kernel<W>, grid, block, lds_bytes, st, d_bases, d_qual, d_off, upatl, n, ctx->prm.seedl, QS,
+                       (int)(ctx->prm.scores != 0), out.words, out.seeds, out.qrows, out.patl);
 }
 
-int rh_launch_pack(real_hip_ctx *ctx, const uint8_t *d_bases, const uint8_t *d_qual, const uint64_t *d_off,
-                   uint32_t upatl, uint64_t n, uint32_t W, uint32_t QS)
+int rh_launch_pack(real_hip_ctx *ctx, hipStream_t st, const uint8_t *d_bases, const uint8_t *d_qual, const uint64_t *d_off,
+                   uint32_t upatl, uint64_t n, uint32_t W, uint32_t QS, const PackOut &out)
 {
     if (!n) return REAL_HIP_OK;
-    RhTimer tm(ctx, REAL_HIP_K_PACK);
+    rh_time_begin(ctx, st, REAL_HIP_K_PACK);
     switch (W) {
-    case 1: launch_pack_w<1>(ctx, d_bases, d_qual, d_off, upatl, n, QS); break;
-    case 2: launch_pack_w<2>(ctx, d_bases, d_qual, d_off, upatl, n, QS); break;
-    case 3: launch_pack_w<3>(ctx, d_bases, d_qual, d_off, upatl, n, QS); break;
-    case 4: launch_pack_w<4>(ctx, d_bases, d_qual, d_off, upatl, n, QS); break;
-    case 5: launch_pack_w<5>(ctx, d_bases, d_qual, d_off, upatl, n, QS); break;
-    case 6: launch_pack_w<6>(ctx, d_bases, d_qual, d_off, upatl, n, QS); break;
-    case 7: launch_pack_w<7>(ctx, d_bases, d_qual, d_off, upatl, n, QS); break;
-    case 8: launch_pack_w<8>(ctx, d_bases, d_qual, d_off, upatl, n, QS); break;
+    case 1: launch_pack_w<1>(ctx, st, d_bases, d_qual, d_off, upatl, n, QS, out); break;
+    case 2: launch_pack_w<2>(ctx, st, d_bases, d_qual, d_off, upatl, n, QS, out); break;
+    case 3: launch_pack_w<3>(ctx, st, d_bases, d_qual, d_off, upatl, n, QS, out); break;
+    case 4: launch_pack_w<4>(ctx, st, d_bases, d_qual, d_off, upatl, n, QS, out); break;
+    case 5: launch_pack_w<5>(ctx, st, d_bases, d_qual, d_off, upatl, n, QS, out); break;
+    case 6: launch_pack_w<6>(ctx, st, d_bases, d_qual, d_off, upatl, n, QS, out); break;
+    case 7: launch_pack_w<7>(ctx, st, d_bases, d_qual, d_off, upatl, n, QS, out); break;
+    case 8: launch_pack_w<8>(ctx, st, d_bases, d_qual, d_off, upatl, n, QS, out); break;
     default: return rh_fail(ctx, REAL_HIP_E_UNSUPPORTED, "read longer than REAL_HIP_MAX_PATL", hipSuccess);
     }
+    rh_time_end(ctx, st);
     RH_HIP(ctx, hipGetLastError());
     return REAL_HIP_OK;
 }

@@ -54,6 +54,38 @@ RhTimer::~RhTimer()
     }
 }
 
+// asynchronous timing: one event pair per launch, resolved (elapsed time read) after the next sync
+static hipEvent_t rh_event(real_hip_ctx *c)
+{
+    if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+void rh_time_begin(real_hip_ctx *c, hipStream_t st, int which)
+{
+    if (!c->timing) return;
+    real_hip_ctx::Pending p; p.a = rh_event(c); p.b = nullptr; p.which = which;
+    (void)hipEventRecord(p.a, st);
+    c->pending.push_back(p);
+}
+void rh_time_end(real_hip_ctx *c, hipStream_t st)
+{
+    if (!c->timing || c->pending.empty()) return;
+    for (size_t i = c->pending.size(); i-- > 0;)
+        if (!c->pending[i].b) { c->pending[i].b = rh_event(c); (void)hipEventRecord(c->pending[i].b, st); break; }
+}
+void rh_time_resolve(real_hip_ctx *c)
+{
+    for (auto &p : c->pending) {
+        float ms = 0.f;
+        if (p.a && p.b && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { c->k_ms[p.which] += ms; c->k_n[p.which] += 1; }
+        if (p.a) c->ev_pool.push_back(p.a);
+        if (p.b) c->ev_pool.push_back(p.b);
+    }
+    c->pending.clear();
+}
+
 extern "C" const char *real_hip_strerror(int s)
 {
     switch (s) {
@@ -140,7 +172,16 @@ extern "C" int real_hip_create(real_hip_ctx **out, const real_hip_params *p)
     do {
         if (hipSetDevice(c->device) != hipSuccess) { rc = REAL_HIP_E_DEVICE; break; }
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = REAL_HIP_E_DEVICE; break; }
+        if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { rc = REAL_HIP_E_DEVICE; break; }
         if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { rc = REAL_HIP_E_DEVICE; break; }
+        {
+            bool ok = true;
+            for (int i = 0; i < 2; ++i)
+                ok = ok && hipEventCreateWithFlags(&c->ev_packed[i], hipEventDisableTiming) == hipSuccess &&
+                     hipEventCreateWithFlags(&c->ev_matched[i], hipEventDisableTiming) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&c->ev_staged, hipEventDisableTiming) == hipSuccess;
+            if (!ok) { rc = REAL_HIP_E_DEVICE; break; }
+        }
         if ((rc = rh_reserve(c, c->LL, 1024 * sizeof(double)))) break;
         if ((rc = rh_reserve(c, c->counters, (size_t)(RH_CSTRIPES + 1) * 16 * sizeof(uint64_t)))) break;
         if (hipMemcpy(c->LL.p, p->LL, 1024 * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { rc = REAL_HIP_E_DEVICE; break; }
@@ -161,6 +202,12 @@ extern "C" void real_hip_destroy(real_hip_ctx *c)
                      &c->keys_b, &c->vals_a, &c->vals_b, &c->sort_tmp, &c->hit_off, &c->s_hits};
     for (DevBuf *b : all) rh_release(*b);
     for (int k = 0; k < 6; ++k) { rh_release(c->ent[k]); rh_release(c->bkt[k]); }
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    rh_time_resolve(c);
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    for (int i = 0; i < 2; ++i) { if (c->ev_packed[i]) (void)hipEventDestroy(c->ev_packed[i]); if (c->ev_matched[i]) (void)hipEventDestroy(c->ev_matched[i]); }
+    if (c->ev_staged) (void)hipEventDestroy(c->ev_staged);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -384,14 +431,31 @@ static int stage_batch(real_hip_ctx *ctx, const real_hip_batch *b, Staged &s)
     s.W = (s.maxpatl + 31) / 32;
     if (s.W < 1) s.W = 1;
     s.QS = 32 * s.W;
-    if ((rc = rh_reserve(ctx, ctx->words, n * 2 * s.W * 8))) return rc;
-    if ((rc = rh_reserve(ctx, ctx->seeds, n * 4 * 8))) return rc;
-    if ((rc = rh_reserve(ctx, ctx->patl, n * 4))) return rc;
-    if (ctx->prm.scores && (rc = rh_reserve(ctx, ctx->qrows, n * 2 * (size_t)s.QS))) return rc;
-    return rh_launch_pack(ctx, s.bases, s.qual, s.off, s.upatl, n, s.W, s.QS);
+    return REAL_HIP_OK;
 }
 
-static void fill_args(real_hip_ctx *ctx, const Staged &s, uint64_t n, MatchArgs &a)
+// packed form of `cap` reads (x `nbuf` buffers)
+static int reserve_packed(real_hip_ctx *ctx, const Staged &s, uint64_t cap, int nbuf)
+{
+    int rc;
+    if ((rc = rh_reserve(ctx, ctx->words, (size_t)nbuf * cap * 2 * s.W * 8))) return rc;
+    if ((rc = rh_reserve(ctx, ctx->seeds, (size_t)nbuf * cap * 4 * 8))) return rc;
+    if ((rc = rh_reserve(ctx, ctx->patl, (size_t)nbuf * cap * 4))) return rc;
+    if (ctx->prm.scores && (rc = rh_reserve(ctx, ctx->qrows, (size_t)nbuf * cap * 2 * (size_t)s.QS))) return rc;
+    return REAL_HIP_OK;
+}
+
+static PackOut packed_at(real_hip_ctx *ctx, const Staged &s, uint64_t first_read)
+{
+    PackOut o;
+    o.words = (uint64_t *)ctx->words.p + first_read * 2 * s.W;
+    o.seeds = (uint64_t *)ctx->seeds.p + first_read * 4;
+    o.patl = (uint32_t *)ctx->patl.p + first_read;
+    o.qrows = ctx->qrows.p ? (uint8_t *)ctx->qrows.p + first_read * 2 * (size_t)s.QS : nullptr;
+    return o;
+}
+
+static void fill_args(real_hip_ctx *ctx, const Staged &s, uint64_t n, const PackOut &pk, MatchArgs &a)
 {
     memset(&a, 0, sizeof a);
     a.t.text = (const uint64_t *)ctx->text.p; a.t.wild = (const uint64_t *)ctx->wild.p;
@@ -402,8 +466,7 @@ static void fill_args(real_hip_ctx *ctx, const Staged &s, uint64_t n, MatchArgs 
     a.ix.n = ctx->n_entries; a.ix.pb = pb;
     rh_index_geometry(l, pb, &a.ix.pshift, &a.ix.fshift, &a.ix.fbits, &a.ix.pbits);
     a.ix.fine = ctx->fine ? 1u : 0u;
-    a.b.words = (const uint64_t *)ctx->words.p; a.b.seeds = (const uint64_t *)ctx->seeds.p;
-    a.b.qrows = (const uint8_t *)ctx->qrows.p; a.b.patl = (const uint32_t *)ctx->patl.p;
+    a.b.words = pk.words; a.b.seeds = pk.seeds; a.b.qrows = pk.qrows; a.b.patl = pk.patl;
     a.b.n_reads = n; a.b.W = s.W; a.b.QS = s.QS;
     a.LL = (const double *)ctx->LL.p;
     a.counters = (unsigned long long *)ctx->counters.p;
@@ -433,15 +496,40 @@ extern "C" int real_hip_match_unique(real_hip_ctx *ctx, const real_hip_batch *b,
             d_score = (float *)ctx->s_score.p;
         }
     }
-    MatchArgs a;
-    fill_args(ctx, s, n, a);
-    a.info = d_info; a.score = d_score;
-    if ((rc = rh_launch_match(ctx, a, false))) return rc;
+    // Chunked two-stream pipeline: the packer (HBM streaming bound) of chunk c+1 runs on its own stream
+    // beside the matcher (random-request bound) of chunk c; two packed buffers, events order the reuse.
+    // (default: one chunk -- measured on MI355X the overlap buys nothing, both kernels load the same memory
+    //  system; REAL_HIP_CHUNK_READS turns the pipeline on, it also halves the packed-buffer footprint)
+    uint64_t CH = n;
+    if (const char *e = getenv("REAL_HIP_CHUNK_READS")) { uint64_t v = strtoull(e, nullptr, 10); if (v >= 1024) CH = v; }
+    if (CH > n) CH = n;
+    const uint64_t nchunks = (n + CH - 1) / CH;
+    if ((rc = reserve_packed(ctx, s, CH, nchunks > 1 ? 2 : 1))) return rc;
+    RH_HIP(ctx, hipEventRecord(ctx->ev_staged, ctx->stream));      // host->device staging copies (if any) precede the packer
+    RH_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_staged, 0));
+    for (uint64_t c = 0; c < nchunks; ++c) {
+        const uint64_t r0 = c * CH, m = (r0 + CH <= n) ? CH : (n - r0);
+        const int bsel = (int)(c & 1);
+        const PackOut pk = packed_at(ctx, s, (uint64_t)bsel * CH);
+        if (c >= 2) RH_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_matched[bsel], 0)); // buffer free again
+        const uint8_t *cb = s.off ? s.bases : s.bases + r0 * (uint64_t)s.upatl;
+        const uint8_t *cq = s.qual ? (s.off ? s.qual : s.qual + r0 * (uint64_t)s.upatl) : nullptr;
+        if ((rc = rh_launch_pack(ctx, ctx->stream2, cb, cq, s.off ? s.off + r0 : nullptr, s.upatl, m, s.W, s.QS, pk))) return rc;
+        RH_HIP(ctx, hipEventRecord(ctx->ev_packed[bsel], ctx->stream2));
+        RH_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_packed[bsel], 0));
+        MatchArgs a;
+        fill_args(ctx, s, m, pk, a);
+        a.info = d_info + r0; a.score = d_score ? d_score + r0 : nullptr;
+        if ((rc = rh_launch_match(ctx, a, false))) return rc;
+        RH_HIP(ctx, hipEventRecord(ctx->ev_matched[bsel], ctx->stream));
+    }
     if (!b->on_device) {
         RH_HIP(ctx, hipMemcpyAsync(info, d_info, n * 8, hipMemcpyDeviceToHost, ctx->stream));
         if (sc) RH_HIP(ctx, hipMemcpyAsync(score, d_score, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     }
+    RH_HIP(ctx, hipStreamSynchronize(ctx->stream2));
     RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    rh_time_resolve(ctx);
     return REAL_HIP_OK;
 }
 
@@ -460,8 +548,11 @@ extern "C" int real_hip_match_all(real_hip_ctx *ctx, const real_hip_batch *b, re
     if ((rc = rh_reserve(ctx, ctx->raw, (cap ? cap : 1) * sizeof(uint4)))) return rc;
     unsigned long long n_raw = 0;
     if (n) {
+        if ((rc = reserve_packed(ctx, s, n, 1))) return rc;
+        const PackOut pk = packed_at(ctx, s, 0);
+        if ((rc = rh_launch_pack(ctx, ctx->stream, s.bases, s.qual, s.off, s.upatl, n, s.W, s.QS, pk))) return rc;
         MatchArgs a;
-        fill_args(ctx, s, n, a);
+        fill_args(ctx, s, n, pk, a);
         a.raw = (uint4 *)ctx->raw.p; a.raw_count = (unsigned long long *)ctx->raw_count.p; a.raw_cap = cap;
         if ((rc = rh_launch_match(ctx, a, true))) return rc;
         RH_HIP(ctx, hipMemcpyAsync(&n_raw, ctx->raw_count.p, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -486,6 +577,7 @@ extern "C" int real_hip_match_all(real_hip_ctx *ctx, const real_hip_batch *b, re
         if (hit_offsets) RH_HIP(ctx, hipMemcpyAsync(hit_offsets, d_off, (n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
     }
     RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    rh_time_resolve(ctx);
     return REAL_HIP_OK;
 }
 

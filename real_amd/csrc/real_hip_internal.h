@@ -92,7 +92,9 @@ struct DevBuf {
 struct real_hip_ctx {
     real_hip_params prm;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;  // matcher (and everything else)
+    hipStream_t stream2 = nullptr; // packer of the next chunk, overlapped with the matcher
+    hipEvent_t ev_packed[2] = {nullptr, nullptr}, ev_matched[2] = {nullptr, nullptr}, ev_staged = nullptr;
     std::string last_error;
 
     // text
@@ -123,6 +125,10 @@ struct real_hip_ctx {
     double   k_ms[REAL_HIP_K_COUNT] = {0, 0, 0, 0, 0};
     uint64_t k_n[REAL_HIP_K_COUNT] = {0, 0, 0, 0, 0};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // asynchronous timing of pipelined launches: event pairs resolved at the next synchronisation point
+    struct Pending { hipEvent_t a, b; int which; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> ev_pool;
 };
 
 // error plumbing: never throw across the ABI
@@ -143,10 +149,15 @@ struct RhTimer { // HIP events on the ctx stream around a group of launches
 };
 
 // ---- kernels launchers (match_kernels.hip) -----------------------------------
-int rh_launch_pack(real_hip_ctx *ctx, const uint8_t *d_bases, const uint8_t *d_qual,
+struct PackOut { uint64_t *words; uint64_t *seeds; uint8_t *qrows; uint32_t *patl; };
+int rh_launch_pack(real_hip_ctx *ctx, hipStream_t st, const uint8_t *d_bases, const uint8_t *d_qual,
                    const uint64_t *d_off, uint32_t uniform_patl, uint64_t n_reads,
-                   uint32_t W, uint32_t QS);
+                   uint32_t W, uint32_t QS, const PackOut &out);
 int rh_launch_match(real_hip_ctx *ctx, const MatchArgs &a, bool all);
+// asynchronous kernel timing (no host synchronisation at the launch site)
+void rh_time_begin(real_hip_ctx *ctx, hipStream_t st, int which);
+void rh_time_end(real_hip_ctx *ctx, hipStream_t st);
+void rh_time_resolve(real_hip_ctx *ctx); // call after the streams were synchronised
 int rh_max_patl(real_hip_ctx *ctx, const uint64_t *d_off, uint64_t n_reads, uint32_t *out);
 int rh_all_finish(real_hip_ctx *ctx, uint64_t n_raw, uint64_t n_reads, real_hip_hit *d_out,
                   uint64_t *d_hit_offsets);
