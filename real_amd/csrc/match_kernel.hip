@@ -27,6 +27,10 @@
 
 #define EB 8  // index entries a lane requests per round trip while enumerating equal ranges
 #define MQ 16 // candidate queue slots per lane (LDS); a full queue is drained and refilled
+#define NPEND 2      // verified locations a lane parks until their scores are computed (flush_pending)
+#define PEND_EV 32   // update() events parked with them
+#define SLOT_NONE 3u
+#define PEND_OVF 0xffu // p_n of a read that needs more slots: matched again by the repeat kernel
 
 template <int W, bool SCORES, bool ALL>
 struct LaneState {
@@ -47,16 +51,153 @@ struct LaneState {
     float cscore;
     bool cok;
     uint32_t crpos, ckk; // last seed window looked at and its per-segment mismatch counts (4 x 8 bits)
+    // SCORES: verified locations whose score is still to be computed, and the update() events that refer
+    // to them, in event order (see flush_pending)
+    uint32_t p_pos[NPEND], p_meta[NPEND]; // text position; k | strand << 8 | fragment << 16
+    uint64_t p_tw[W];                     // aligned text words of pending location 0
+    uint32_t p_n, p_nev, p_ev, cslot;     // locations, events, 1 bit per event (= location), slot of the memo
     // work counters
     unsigned cL, cP, cC, cS, cH, cV;
 };
 
+
+// revcomp of a read held as W words of 32 bases: out[i] = 3 - in[patl-1-i] (Pattern.hpp:105-128)
+template <int W>
+__device__ __forceinline__ void revcomp_words(const uint64_t *in, uint64_t *out, uint32_t patl)
+{
+    const uint32_t nw = (patl + 31) >> 5;
+    const uint32_t pad = 64 * nw - 2 * patl; // 0..62
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        uint64_t x = 0, y = 0;
+#pragma unroll
+        for (int k = 0; k < W; ++k) { // rev2(in[nw-1-j]), rev2(in[nw-2-j]) with register-static indices
+            if ((uint32_t)k + (uint32_t)j + 1 == nw) x = rev2(in[k]);
+            if ((uint32_t)k + (uint32_t)j + 2 == nw) y = rev2(in[k]);
+        }
+        const uint64_t v = pad ? ((x << pad) | (y >> (64 - pad))) : x;
+        const uint64_t valid = ((uint32_t)j + 1 < nw) ? ~0ull : ((uint32_t)j + 1 == nw ? (~0ull << pad) : 0ull);
+        out[j] = ~v & valid;
+    }
+}
+
+// ComputeScore<...,true>::computeScore, ComputeScore.hpp:50-190: sequential FP64 sum in base order
+// starting at 1.0, cast to float once.  Ow = oriented read, tw = text aligned to the read, qp = the
+// oriented quality row.
+template <int W>
+__device__ __forceinline__ float score_location(const double *sLL, const uint64_t *Ow, const uint64_t *tw, uint32_t patl,
+                                                const uint8_t *__restrict__ qp)
+{
+    double raw = 1.0;
+    // 16 bases per step in a real (not unrolled) loop: the adds are one dependent chain, and a fully
+    // unrolled body lets the scheduler hoist every table read in front of it (1 wave per SIMD).  The
+    // per-step operands sit in registers and are rotated down by one slot per step, which keeps all
+    // register indices static.
+    constexpr int NQ = 2 * W;
+    uint32_t th[NQ], oh[NQ];
+#pragma unroll
+    for (int c = 0; c < NQ; ++c) {
+        th[c] = (uint32_t)(tw[c >> 1] >> ((c & 1) ? 0 : 32));
+        oh[c] = (uint32_t)(Ow[c >> 1] >> ((c & 1) ? 0 : 32));
+    }
+    constexpr bool BATCHQ = (W <= 4); // short reads: all quality chunks in flight together (one round trip)
+    uint4 qv[BATCHQ ? NQ : 1];
+    if (BATCHQ) {
+#pragma unroll
+        for (int c = 0; c < NQ; ++c)
+            qv[c] = (16u * c < patl) ? *reinterpret_cast<const uint4 *>(qp + 16 * c) : make_uint4(0, 0, 0, 0);
+    }
+    const uint32_t nchunk = (patl + 15) >> 4;
+#pragma unroll 1
+    for (uint32_t c = 0; c < nchunk; ++c) {
+        const uint4 q4 = BATCHQ ? qv[0] : *reinterpret_cast<const uint4 *>(qp + 16 * c);
+        const uint32_t qa[4] = {q4.x, q4.y, q4.z, q4.w};
+        const uint32_t lim = min(16u, patl - 16u * c);
+        const uint32_t tr = th[0], rr = oh[0];
+#pragma unroll
+        for (uint32_t u = 0; u < 16; ++u) {
+            if (u < lim) {
+                const uint32_t ref = (tr >> (30 - 2 * u)) & 3;
+                const uint32_t rb = (rr >> (30 - 2 * u)) & 3;
+                const uint32_t q = (qa[u >> 2] >> (8 * (u & 3))) & 0xff;
+                raw += sLL[((ref << 8) | (rb << 6) | q) & 1023];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i + 1 < NQ; ++i) {
+            th[i] = th[i + 1]; oh[i] = oh[i + 1];
+            if (BATCHQ) qv[i] = qv[i + 1];
+        }
+    }
+    return (float)raw;
+}
+
+// the update() call itself: the best/unique fold, or the matchAll append
+template <int W, bool SCORES, bool ALL>
+__device__ __forceinline__ void deliver(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, uint32_t pos, uint32_t meta, float score)
+{
+    if (ALL) {
+        unsigned long long slot = wave_append_slot(a.raw_count);
+        if (slot < a.raw_cap) a.raw[slot] = make_uint4((uint32_t)s.r, pos, __float_as_uint(score), meta);
+    } else {
+        fold_update<SCORES>((meta >> 8) & 1, a.t.fileid, pos, meta & 0xff, score, s.eps, meta >> 16, s.info, s.iscore);
+    }
+}
+
+// Scores of the parked locations, then their update() events in the order they occurred.  The score is
+// ~1000 instructions of which every lane of a wave needs one or two per read, but at different points
+// of its candidate loop: computed where the hit is found, the wave would run that code once per
+// distinct point (5-6 times per wave, mostly idle lanes).  Parked, the lanes score together at the end
+// of the read; the fold sees the same events in the same order.  A read that needs more slots
+// (repeat-rich) is handed to the repeat kernel, which scores in place.
+template <int W, bool SCORES, bool ALL>
+__device__ __forceinline__ void flush_pending(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL)
+{
+    float sc[NPEND] = {1.0f, 1.0f};
+#pragma unroll 1
+    for (uint32_t j = 0; j < s.p_n; ++j) {
+        const uint32_t pos = j ? s.p_pos[1] : s.p_pos[0], meta = j ? s.p_meta[1] : s.p_meta[0];
+        const uint32_t inv = (meta >> 8) & 1;
+        uint64_t Ow[W], tw[W];
+        if ((int)inv == s.inv) {
+#pragma unroll
+            for (int i = 0; i < W; ++i) Ow[i] = s.O[i];
+        } else {
+            revcomp_words<W>(s.O, Ow, s.patl);
+        }
+        if (j == 0) {
+#pragma unroll
+            for (int i = 0; i < W; ++i) tw[i] = s.p_tw[i];
+        } else { // second location of a read: the text is read again
+            const uint64_t wi = pos >> 5;
+            const unsigned sh = 2u * (pos & 31);
+            uint64_t t[W + 2];
+#pragma unroll
+            for (int i = 0; i <= W; i += 2) {
+                U64x2 p2 = {0ull, 0ull};
+                if ((uint32_t)i <= s.nw) p2 = load2(a.t.text + wi + i);
+                t[i] = p2.a; t[i + 1] = p2.b;
+            }
+#pragma unroll
+            for (int i = 0; i < W; ++i) tw[i] = sh ? ((t[i] << sh) | (t[i + 1] >> (64 - sh))) : t[i];
+        }
+        const float v = score_location<W>(sLL, Ow, tw, s.patl, a.b.qrows + s.r * (2ull * a.b.QS) + (uint64_t)inv * a.b.QS);
+        if (j) sc[1] = v; else sc[0] = v;
+    }
+#pragma unroll 1
+    for (uint32_t e = 0; e < s.p_nev; ++e) {
+        const uint32_t j = (s.p_ev >> e) & 1u;
+        deliver<W, SCORES, ALL>(a, s, j ? s.p_pos[1] : s.p_pos[0], j ? s.p_meta[1] : s.p_meta[0], j ? sc[1] : sc[0]);
+    }
+}
+
 // one member of a bucket whose fingerprint equals the read's: the body of the candidate loop
 // of ::match (match.hpp:383-413)
-template <int W, bool SCORES, bool ALL>
+template <int W, bool SCORES, bool ALL, bool DEFER>
 __device__ __forceinline__ void process_candidate(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL,
                                                   uint32_t rpos, int la)
 {
+    if (SCORES && DEFER && s.p_n == PEND_OVF) return; // handed to the repeat kernel
     const uint64_t *__restrict__ T = a.t.text;
     const uint32_t bb = a.b_bits;
     const uint64_t mb = (bb >= 64) ? ~0ull : ((1ull << bb) - 1);
@@ -86,6 +227,8 @@ __device__ __forceinline__ void process_candidate(const MatchArgs &a, LaneState<
     s.cS++;
     if (rpos < s.so) return; // match.hpp:393
     const uint32_t pos = rpos - s.so;
+    bool reg = false; // a location verified here for the first time
+    uint64_t twl[W];
     if (pos != s.cpos) {
         s.cpos = pos;
         s.cok = false;
@@ -119,72 +262,43 @@ __device__ __forceinline__ void process_candidate(const MatchArgs &a, LaneState<
         }
         if (total > a.totalkmax) return;
         float sc = 1.0f; // ComputeScore<...,false>, ComputeScore.hpp:31-45
-        if (SCORES) {
-            // ComputeScore<...,true>::computeScore, ComputeScore.hpp:50-190: sequential FP64 sum in
-            // base order starting at 1.0, cast to float once.
-            double raw = 1.0;
-            const uint8_t *__restrict__ qp = a.b.qrows + s.r * (2ull * a.b.QS) + (uint64_t)s.inv * a.b.QS;
-            // 16 bases per step in a real (not unrolled) loop: the adds are one dependent chain, and a fully
-            // unrolled body lets the scheduler hoist every table read in front of it (1 wave per SIMD).  The
-            // per-step operands sit in registers and are rotated down by one slot per step, which keeps all
-            // register indices static.
-            constexpr int NQ = 2 * W;
-            uint32_t th[NQ], oh[NQ];
+        if (SCORES && !DEFER)
+            sc = score_location<W>(sLL, s.O, tw, s.patl, a.b.qrows + s.r * (2ull * a.b.QS) + (uint64_t)s.inv * a.b.QS);
+        if (SCORES && DEFER) { // the score is computed later: flush_pending
 #pragma unroll
-            for (int c = 0; c < NQ; ++c) {
-                th[c] = (uint32_t)(tw[c >> 1] >> ((c & 1) ? 0 : 32));
-                oh[c] = (uint32_t)(s.O[c >> 1] >> ((c & 1) ? 0 : 32));
-            }
-            constexpr bool BATCHQ = (W <= 4); // short reads: all quality chunks in flight together (one round trip)
-            uint4 qv[BATCHQ ? NQ : 1];
-            if (BATCHQ) {
-#pragma unroll
-                for (int c = 0; c < NQ; ++c)
-                    qv[c] = (16u * c < s.patl) ? *reinterpret_cast<const uint4 *>(qp + 16 * c) : make_uint4(0, 0, 0, 0);
-            }
-            const uint32_t nchunk = (s.patl + 15) >> 4;
-#pragma unroll 1
-            for (uint32_t c = 0; c < nchunk; ++c) {
-                const uint4 q4 = BATCHQ ? qv[0] : *reinterpret_cast<const uint4 *>(qp + 16 * c);
-                const uint32_t qa[4] = {q4.x, q4.y, q4.z, q4.w};
-                const uint32_t lim = min(16u, s.patl - 16u * c);
-                const uint32_t tr = th[0], rr = oh[0];
-#pragma unroll
-                for (uint32_t u = 0; u < 16; ++u) {
-                    if (u < lim) {
-                        const uint32_t ref = (tr >> (30 - 2 * u)) & 3;
-                        const uint32_t rb = (rr >> (30 - 2 * u)) & 3;
-                        const uint32_t q = (qa[u >> 2] >> (8 * (u & 3))) & 0xff;
-                        raw += sLL[((ref << 8) | (rb << 6) | q) & 1023];
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i + 1 < NQ; ++i) {
-                    th[i] = th[i + 1]; oh[i] = oh[i + 1];
-                    if (BATCHQ) qv[i] = qv[i + 1];
-                }
-            }
-            sc = (float)raw;
+            for (int j = 0; j < W; ++j) twl[j] = tw[j];
+            reg = true;
         }
-        s.cok = true; s.ck = total; s.cscore = sc; s.cfrag = frag;
+        s.cok = true; s.ck = total; s.cscore = sc; s.cfrag = frag; s.cslot = SLOT_NONE;
     }
     if (!s.cok) return;
     s.cH++; // one updater::update call, match.hpp:411
+    bool emit = true;
     if (ALL) {
         // unifyMatches (matchAllImplementation.cpp:150-161) only removes exact duplicates: the same
         // (strand,pos) reached through a later list.  A hit is kept iff la is the first list whose two
         // segments are mismatch free.
         const bool z0 = !k0, z1 = !k1, z2 = !k2, z3 = !k3;
         const int first = (z0 && z1) ? 0 : (z0 && z2) ? 1 : (z0 && z3) ? 2 : (z1 && z2) ? 3 : (z1 && z3) ? 4 : 5;
-        if (first == la) {
-            unsigned long long slot = wave_append_slot(a.raw_count);
-            if (slot < a.raw_cap)
-                a.raw[slot] = make_uint4((uint32_t)s.r, s.cpos, __float_as_uint(s.cscore),
-                                         s.ck | ((uint32_t)s.inv << 8) | (s.cfrag << 16));
-        }
-    } else {
-        fold_update<SCORES>(s.inv != 0, a.t.fileid, s.cpos, s.ck, s.cscore, s.eps, s.cfrag, s.info, s.iscore);
+        emit = (first == la);
     }
+    const uint32_t meta = s.ck | ((uint32_t)s.inv << 8) | (s.cfrag << 16);
+    if (!(SCORES && DEFER)) {
+        if (emit) deliver<W, SCORES, ALL>(a, s, s.cpos, meta, s.cscore);
+        return;
+    }
+    // park the location (once) and the event; out of room => the read goes to the repeat kernel
+    if ((reg && s.p_n == NPEND) || (emit && s.p_nev == PEND_EV)) { s.p_n = PEND_OVF; return; }
+    if (reg) {
+        if (s.p_n) { s.p_pos[1] = s.cpos; s.p_meta[1] = meta; }
+        else {
+            s.p_pos[0] = s.cpos; s.p_meta[0] = meta;
+#pragma unroll
+            for (int j = 0; j < W; ++j) s.p_tw[j] = twl[j];
+        }
+        s.cslot = s.p_n++;
+    }
+    if (emit) { s.p_ev |= s.cslot << s.p_nev; s.p_nev++; }
 }
 
 // Scan of the buckets of lists [LA0, LA1) of one strand; pushes the entries that survive the key
@@ -307,7 +421,7 @@ __device__ __forceinline__ bool scan_lists(const MatchArgs &a, LaneState<W, SCOR
 // equal ranges of all lists in list order -- the canonical candidate order -- four entries per round trip,
 // applies the partner filter and queues the survivors; a full queue is drained and refilled (the only
 // state across a drain is the enumeration offset).
-template <int W, bool SCORES, bool ALL, int LA0, int LA1>
+template <int W, bool SCORES, bool ALL, bool DEFER, int LA0, int LA1>
 __device__ __forceinline__ void match_lists_fine(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL,
                                                  uint32_t *q_pos, uint8_t *q_la)
 {
@@ -356,7 +470,7 @@ __device__ __forceinline__ void match_lists_fine(const MatchArgs &a, LaneState<W
     }
     s.cC += total; s.cP += total;
     // 2. enumerate, filter, queue, drain
-    for (uint32_t kb = 0; kb < total; kb += MQ) {
+    for (uint32_t kb = 0; kb < total && !(DEFER && s.p_n == PEND_OVF); kb += MQ) {
         const uint32_t kend = min(total, kb + (uint32_t)MQ);
         uint32_t qn = 0;
         for (uint32_t k0 = kb; k0 < kend; k0 += EB) {
@@ -395,31 +509,36 @@ __device__ __forceinline__ void match_lists_fine(const MatchArgs &a, LaneState<W
         }
         // 3. verify / score / fold in candidate order
         for (uint32_t k = 0; k < qn; ++k)
-            process_candidate<W, SCORES, ALL>(a, s, sLL, q_pos[k * 256 + threadIdx.x], (int)q_la[k * 256 + threadIdx.x]);
+            process_candidate<W, SCORES, ALL, DEFER>(a, s, sLL, q_pos[k * 256 + threadIdx.x], (int)q_la[k * 256 + threadIdx.x]);
     }
 }
 
 // lists [LA0, LA1) of one strand
-template <int W, bool SCORES, bool ALL, bool FINE, int LA0, int LA1>
+template <int W, bool SCORES, bool ALL, bool FINE, bool DEFER, int LA0, int LA1>
 __device__ __forceinline__ void match_lists(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL,
                                             uint32_t *q_pos, uint8_t *q_la, uint32_t *q_cur)
 {
-    if (FINE) { match_lists_fine<W, SCORES, ALL, LA0, LA1>(a, s, sLL, q_pos, q_la); return; }
+    if (FINE) { match_lists_fine<W, SCORES, ALL, DEFER, LA0, LA1>(a, s, sLL, q_pos, q_la); return; }
     uint32_t donemask = 0, qn = 0;
     bool again = scan_lists<W, SCORES, ALL, FINE, LA0, LA1, true>(a, s, q_pos, q_la, q_cur, donemask, qn);
     // 4. verify / score / fold in candidate order
     for (uint32_t k = 0; k < qn; ++k)
-        process_candidate<W, SCORES, ALL>(a, s, sLL, q_pos[k * 256 + threadIdx.x], (int)q_la[k * 256 + threadIdx.x]);
+        process_candidate<W, SCORES, ALL, DEFER>(a, s, sLL, q_pos[k * 256 + threadIdx.x], (int)q_la[k * 256 + threadIdx.x]);
     while (again) {
         again = scan_lists<W, SCORES, ALL, FINE, LA0, LA1, false>(a, s, q_pos, q_la, q_cur, donemask, qn);
         for (uint32_t k = 0; k < qn; ++k)
-            process_candidate<W, SCORES, ALL>(a, s, sLL, q_pos[k * 256 + threadIdx.x], (int)q_la[k * 256 + threadIdx.x]);
+            process_candidate<W, SCORES, ALL, DEFER>(a, s, sLL, q_pos[k * 256 + threadIdx.x], (int)q_la[k * 256 + threadIdx.x]);
     }
 }
 
-template <int W, bool SCORES, bool ALL, bool FINE>
+// REPEAT = false: the matcher proper, lane i of the grid takes read i.  With scores on it parks hits and scores
+// them at the end of the read (DEFER); a read that needs more than NPEND locations / PEND_EV events is left
+// untouched and its index appended to a.ovf_list.  REPEAT = true: the same matcher with in-place scoring over
+// the reads of a.ovf_list (grid-stride; the list length is read from device memory, no host round trip).
+template <int W, bool SCORES, bool ALL, bool FINE, bool REPEAT>
 __global__ __launch_bounds__(256) void match_kernel(MatchArgs a)
 {
+    constexpr bool DEFER = SCORES && !REPEAT;
     __shared__ double sLL[SCORES ? 1024 : 1];
     __shared__ uint32_t q_pos[MQ * 256];
     __shared__ uint8_t q_la[MQ * 256];
@@ -428,24 +547,27 @@ __global__ __launch_bounds__(256) void match_kernel(MatchArgs a)
         for (int i = threadIdx.x; i < 1024; i += 256) sLL[i] = a.LL[i];
         __syncthreads();
     }
-    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     LaneState<W, SCORES, ALL> s;
     s.cL = s.cP = s.cC = s.cS = s.cH = s.cV = 0;
     unsigned cR = 0;
-    const uint32_t patl = (r < a.b.n_reads) ? a.b.patl[r] : 0u;
-
-    if (patl) {
-        cR = 1;
+    const uint64_t n_items = REPEAT ? (uint64_t)*a.ovf_count : a.b.n_reads;
+    for (uint64_t it = (uint64_t)blockIdx.x * 256 + threadIdx.x; it < n_items; it += REPEAT ? (uint64_t)gridDim.x * 256 : n_items) {
+        const uint64_t r = REPEAT ? (uint64_t)a.ovf_list[it] : it;
+        const uint32_t patl = a.b.patl[r];
+        if (!patl) continue;
+        const unsigned c0[6] = {s.cL, s.cP, s.cC, s.cS, s.cH, s.cV};
         s.r = r; s.patl = patl;
         s.nw = (patl + 31) >> 5;
         s.lastmask = ~0ull << (64 - 2 * (patl - 32 * (s.nw - 1)));
         s.eps = (float)(a.filter_mult * (double)patl); // RealOptions.hpp:74-77
         s.info = 0; s.iscore = 0.f;
+        s.p_n = s.p_nev = s.p_ev = 0; s.cslot = SLOT_NONE;
         if (!ALL) {
             s.info = a.info[r];
             if (SCORES) s.iscore = a.score[r];
         }
         for (int inv = 0; inv < 2; ++inv) {
+            if (DEFER && s.p_n == PEND_OVF) break;
             const uint64_t *wp = a.b.words + r * (2 * W) + inv * W;
 #pragma unroll
             for (int j = 0; j < W; j += 2) {
@@ -463,14 +585,23 @@ __global__ __launch_bounds__(256) void match_kernel(MatchArgs a)
             if (!ALL && !SCORES) {
                 // uni0s / uni0r early-out (matchUniqueImplementation.cpp:434-436, 470-472): lists 1..5 of a
                 // strand are skipped when list 0 left the record in this strand's state with 0 errors
-                match_lists<W, SCORES, ALL, FINE, 0, 1>(a, s, sLL, q_pos, q_la, q_cur);
+                match_lists<W, SCORES, ALL, FINE, DEFER, 0, 1>(a, s, sLL, q_pos, q_la, q_cur);
                 const unsigned st = (unsigned)(s.info >> ST_SHIFT), er = (unsigned)(s.info >> ER_SHIFT) & 15;
                 if (!(st == (unsigned)(inv ? ST_REVERSE : ST_STRAIGHT) && er == 0))
-                    match_lists<W, SCORES, ALL, FINE, 1, 6>(a, s, sLL, q_pos, q_la, q_cur);
+                    match_lists<W, SCORES, ALL, FINE, DEFER, 1, 6>(a, s, sLL, q_pos, q_la, q_cur);
             } else {
-                match_lists<W, SCORES, ALL, FINE, 0, 6>(a, s, sLL, q_pos, q_la, q_cur);
+                match_lists<W, SCORES, ALL, FINE, DEFER, 0, 6>(a, s, sLL, q_pos, q_la, q_cur);
             }
         }
+        if (DEFER && s.p_n == PEND_OVF) {
+            // nothing of this read has been delivered or counted: the repeat kernel does it all
+            const unsigned long long slot = wave_append_slot(a.ovf_count);
+            a.ovf_list[slot] = (uint32_t)r;
+            s.cL = c0[0]; s.cP = c0[1]; s.cC = c0[2]; s.cS = c0[3]; s.cH = c0[4]; s.cV = c0[5];
+            continue;
+        }
+        cR++;
+        if (DEFER) flush_pending<W, SCORES, ALL>(a, s, sLL); // the lanes of the wave score together
         if (!ALL) {
             a.info[r] = s.info;
             if (SCORES) a.score[r] = s.iscore;
@@ -497,36 +628,72 @@ static void launch_match_wf(real_hip_ctx *ctx, const MatchArgs &a, bool all)
     dim3 grid((unsigned)((a.b.n_reads + 255) / 256)), block(256);
     const bool sc = ctx->prm.scores != 0;
     if (all) {
-        if (sc) hipLaunchKernelGGL((match_kernel<W, true, true, FINE>), grid, block, 0, ctx->stream, a);
-        else    hipLaunchKernelGGL((match_kernel<W, false, true, FINE>), grid, block, 0, ctx->stream, a);
+        if (sc) hipLaunchKernelGGL((match_kernel<W, true, true, FINE, false>), grid, block, 0, ctx->stream, a);
+        else    hipLaunchKernelGGL((match_kernel<W, false, true, FINE, false>), grid, block, 0, ctx->stream, a);
     } else {
-        if (sc) hipLaunchKernelGGL((match_kernel<W, true, false, FINE>), grid, block, 0, ctx->stream, a);
-        else    hipLaunchKernelGGL((match_kernel<W, false, false, FINE>), grid, block, 0, ctx->stream, a);
+        if (sc) hipLaunchKernelGGL((match_kernel<W, true, false, FINE, false>), grid, block, 0, ctx->stream, a);
+        else    hipLaunchKernelGGL((match_kernel<W, false, false, FINE, false>), grid, block, 0, ctx->stream, a);
     }
 }
-template <int W>
-static void launch_match_w(real_hip_ctx *ctx, const MatchArgs &a, bool all)
+// reads the matcher handed over (scores on only): far fewer than the batch, so a fixed grid strides over them
+template <int W, bool FINE>
+static void launch_repeat_wf(real_hip_ctx *ctx, const MatchArgs &a, bool all)
 {
+    const uint64_t blocks = (a.b.n_reads + 255) / 256;
+    dim3 grid((unsigned)(blocks < 2048 ? blocks : 2048)), block(256);
+    if (all) hipLaunchKernelGGL((match_kernel<W, true, true, FINE, true>), grid, block, 0, ctx->stream, a);
+    else     hipLaunchKernelGGL((match_kernel<W, true, false, FINE, true>), grid, block, 0, ctx->stream, a);
+}
+template <int W>
+static void launch_match_w(real_hip_ctx *ctx, const MatchArgs &a, bool all, bool repeat)
+{
+    if (repeat) {
+        if (a.ix.fine) launch_repeat_wf<W, true>(ctx, a, all);
+        else launch_repeat_wf<W, false>(ctx, a, all);
+        return;
+    }
     if (a.ix.fine) launch_match_wf<W, true>(ctx, a, all);
     else launch_match_wf<W, false>(ctx, a, all);
 }
 
-int rh_launch_match(real_hip_ctx *ctx, const MatchArgs &a, bool all)
+static int launch_match_any(real_hip_ctx *ctx, const MatchArgs &a, bool all, bool repeat)
 {
-    if (!a.b.n_reads) return REAL_HIP_OK;
-    rh_time_begin(ctx, ctx->stream, all ? REAL_HIP_K_MATCH_ALL : REAL_HIP_K_MATCH_UNIQUE);
     switch (a.b.W) {
-    case 1: launch_match_w<1>(ctx, a, all); break;
-    case 2: launch_match_w<2>(ctx, a, all); break;
-    case 3: launch_match_w<3>(ctx, a, all); break;
-    case 4: launch_match_w<4>(ctx, a, all); break;
-    case 5: launch_match_w<5>(ctx, a, all); break;
-    case 6: launch_match_w<6>(ctx, a, all); break;
-    case 7: launch_match_w<7>(ctx, a, all); break;
-    case 8: launch_match_w<8>(ctx, a, all); break;
+    case 1: launch_match_w<1>(ctx, a, all, repeat); break;
+    case 2: launch_match_w<2>(ctx, a, all, repeat); break;
+    case 3: launch_match_w<3>(ctx, a, all, repeat); break;
+    case 4: launch_match_w<4>(ctx, a, all, repeat); break;
+    case 5: launch_match_w<5>(ctx, a, all, repeat); break;
+    case 6: launch_match_w<6>(ctx, a, all, repeat); break;
+    case 7: launch_match_w<7>(ctx, a, all, repeat); break;
+    case 8: launch_match_w<8>(ctx, a, all, repeat); break;
     default: return rh_fail(ctx, REAL_HIP_E_UNSUPPORTED, "read longer than REAL_HIP_MAX_PATL", hipSuccess);
     }
+    return REAL_HIP_OK;
+}
+
+int rh_launch_match(real_hip_ctx *ctx, const MatchArgs &args, bool all)
+{
+    if (!args.b.n_reads) return REAL_HIP_OK;
+    MatchArgs a = args;
+    const bool sc = ctx->prm.scores != 0;
+    int rc;
+    if (sc) { // hand-over list of the reads the matcher leaves to the repeat kernel
+        if ((rc = rh_reserve(ctx, ctx->ovf_list, a.b.n_reads * 4))) return rc;
+        if ((rc = rh_reserve(ctx, ctx->ovf_count, 8))) return rc;
+        a.ovf_list = (uint32_t *)ctx->ovf_list.p;
+        a.ovf_count = (unsigned long long *)ctx->ovf_count.p;
+        RH_HIP(ctx, hipMemsetAsync(ctx->ovf_count.p, 0, 8, ctx->stream));
+    }
+    rh_time_begin(ctx, ctx->stream, all ? REAL_HIP_K_MATCH_ALL : REAL_HIP_K_MATCH_UNIQUE);
+    if ((rc = launch_match_any(ctx, a, all, false))) return rc;
     rh_time_end(ctx, ctx->stream);
     RH_HIP(ctx, hipGetLastError());
+    if (sc) {
+        rh_time_begin(ctx, ctx->stream, REAL_HIP_K_MATCH_REPEAT);
+        if ((rc = launch_match_any(ctx, a, all, true))) return rc;
+        rh_time_end(ctx, ctx->stream);
+        RH_HIP(ctx, hipGetLastError());
+    }
     return REAL_HIP_OK;
 }

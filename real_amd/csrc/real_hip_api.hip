@@ -198,7 +198,7 @@ extern "C" void real_hip_destroy(real_hip_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->text, &c->wild, &c->frag, &c->LL, &c->counters, &c->s_bases, &c->s_qual, &c->s_off, &c->s_info,
-                     &c->s_score, &c->words, &c->seeds, &c->qrows, &c->patl, &c->maxpatl, &c->raw, &c->raw_count, &c->keys_a,
+                     &c->s_score, &c->words, &c->seeds, &c->qrows, &c->patl, &c->maxpatl, &c->ovf_list, &c->ovf_count, &c->raw, &c->raw_count, &c->keys_a,
                      &c->keys_b, &c->vals_a, &c->vals_b, &c->sort_tmp, &c->hit_off, &c->s_hits};
     for (DevBuf *b : all) rh_release(*b);
     for (int k = 0; k < 6; ++k) { rh_release(c->ent[k]); rh_release(c->bkt[k]); }

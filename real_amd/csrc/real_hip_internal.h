@@ -79,6 +79,9 @@ struct MatchArgs {
     uint4 *raw;            // raw hit records
     unsigned long long *raw_count;
     uint64_t raw_cap;
+    // reads handed from the matcher to the repeat kernel (scores on)
+    uint32_t *ovf_list;
+    unsigned long long *ovf_count;
     double   filter_mult;
     uint32_t l, q, b_bits, seedkmax, totalkmax;
 };
@@ -116,14 +119,14 @@ struct real_hip_ctx {
 
     // batch staging + packed form
     DevBuf s_bases, s_qual, s_off, s_info, s_score;
-    DevBuf words, seeds, qrows, patl, maxpatl;
+    DevBuf words, seeds, qrows, patl, maxpatl, ovf_list, ovf_count;
     // matchAll workspace
     DevBuf raw, raw_count, keys_a, keys_b, vals_a, vals_b, sort_tmp, hit_off, s_hits;
 
     // timing
     bool timing = true;
-    double   k_ms[REAL_HIP_K_COUNT] = {0, 0, 0, 0, 0};
-    uint64_t k_n[REAL_HIP_K_COUNT] = {0, 0, 0, 0, 0};
+    double   k_ms[REAL_HIP_K_COUNT] = {};
+    uint64_t k_n[REAL_HIP_K_COUNT] = {};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // asynchronous timing of pipelined launches: event pairs resolved at the next synchronisation point
     struct Pending { hipEvent_t a, b; int which; };
