@@ -239,7 +239,7 @@ def main():
         step()
     log("warmup done")
     m.counters(reset=True)
-    for k in (rlib.K_PACK, rlib.K_MATCH_UNIQUE):
+    for k in (rlib.K_MATCH_UNIQUE, rlib.K_MATCH_REPEAT):
         m.kernel_time(k, reset=True)
     if world > 1:
         dist.barrier()
@@ -259,7 +259,7 @@ def main():
     log("timed steps done: %.1f ms/step" % (dt / args.steps * 1e3))
     ctr = m.counters()
     match_ms, match_n = m.kernel_time(rlib.K_MATCH_UNIQUE)
-    pack_ms, pack_n = m.kernel_time(rlib.K_PACK)
+    rep_ms, rep_n = m.kernel_time(rlib.K_MATCH_REPEAT)
 
     if rank == 0:
         K = args.steps
@@ -297,7 +297,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "match_kernel<W=%d,scores=%d,unique,fine=%d>" % ((args.patl + 31) // 32, args.scores, int(args.seedl - m.prefix_bits <= 2)), "avg_launch_ms": avg_ms, "launches": match_n,
                          "algorithmic_bytes_per_read": a_total / max(ctr["reads"], 1),
-                         "pack_kernel_avg_ms": pack_ms / max(pack_n, 1),
+                         "repeat_pass_avg_ms": rep_ms / max(rep_n, 1),
                          "work_per_read": {k: ctr[k] / max(ctr["reads"], 1) for k in ("lookups", "probes", "candidates", "seedpass", "hits", "verified")}},
         }
         if world == 1 and not args.no_cpu_baseline:

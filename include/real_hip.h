@@ -178,10 +178,9 @@ int real_hip_counters_get(real_hip_ctx *ctx, real_hip_counters *out, int reset);
 
 /* ---- timing: HIP events recorded on the ctx's own stream around every kernel
  * of the path; times are accumulated per kernel since the last reset.         */
-enum { REAL_HIP_K_PACK = 0, REAL_HIP_K_MATCH_UNIQUE = 1, REAL_HIP_K_MATCH_ALL = 2,
-       REAL_HIP_K_ALL_SORT = 3, REAL_HIP_K_INDEX = 4,
-       REAL_HIP_K_MATCH_REPEAT = 5, /* second pass over the repeat-rich reads the matcher hands over (scores on) */
-       REAL_HIP_K_COUNT = 6 };
+enum { REAL_HIP_K_MATCH_UNIQUE = 0, REAL_HIP_K_MATCH_ALL = 1, REAL_HIP_K_ALL_SORT = 2, REAL_HIP_K_INDEX = 3,
+       REAL_HIP_K_MATCH_REPEAT = 4, /* second pass over the repeat-rich reads the matcher hands over (scores on) */
+       REAL_HIP_K_COUNT = 5 };
 int real_hip_kernel_time(real_hip_ctx *ctx, int which, double *total_ms, uint64_t *launches, int reset);
 int real_hip_timing_enable(real_hip_ctx *ctx, int on);
 

@@ -27,6 +27,10 @@
 
 #define EB 8  // index entries a lane requests per round trip while enumerating equal ranges
 #define MQ 16 // candidate queue slots per lane (LDS); a full queue is drained and refilled
+// LDS bytes of one wave: its candidate queue (MQ x 64 positions + lists, 6 x 64 cursors) while it matches; before
+// and after, the staging area through which it reads the bases / qualities of its reads from the batch
+#define STG_BYTES (MQ * 64u * 5u + 6u * 64u * 4u)
+#define STG_PAD 16u
 #define NPEND 2      // verified locations a lane parks until their scores are computed (flush_pending)
 #define PEND_EV 32   // update() events parked with them
 #define SLOT_NONE 3u
@@ -41,7 +45,7 @@ struct LaneState {
     uint64_t lastmask;
     float eps;
     int inv;
-    uint64_t r;
+    uint64_t r, o0;     // read index; offset of its bytes in the batch arrays
     // result
     uint64_t info;
     float iscore;
@@ -81,12 +85,81 @@ __device__ __forceinline__ void revcomp_words(const uint64_t *in, uint64_t *out,
     }
 }
 
-// ComputeScore<...,true>::computeScore, ComputeScore.hpp:50-190: sequential FP64 sum in base order
-// starting at 1.0, cast to float once.  Ow = oriented read, tw = text aligned to the read, qp = the
-// oriented quality row.
+// ---- the bytes of a read (mapped symbols or qualities) -------------------------------------------------
+// staged by the wave into its LDS region (row at byte offset lb; the region has STG_PAD bytes of slack in
+// front and 4 behind, so a dword that straddles either end of the row is a harmless over-read) ...
+struct LdsRow {
+    const uint8_t *stg;
+    uint32_t lb;
+    __device__ __forceinline__ uint32_t dword(int byteoff, uint32_t) const
+    {
+        const uint32_t o = lb + (uint32_t)byteoff;
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(stg + (o & ~3u));
+        return __builtin_amdgcn_alignbyte(p[1], p[0], o & 3u);
+    }
+};
+// ... or read in place, byte by byte and never outside the row (repeat kernel: few reads, scattered)
+struct GlobalRow {
+    const uint8_t *row;
+    __device__ __forceinline__ uint32_t dword(int byteoff, uint32_t patl) const
+    {
+        uint32_t v = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int i = byteoff + b;
+            if (i >= 0 && i < (int)patl) v |= (uint32_t)row[i] << (8 * b);
+        }
+        return v;
+    }
+};
+
+// mapped symbols -> 32 bases per word, MSB first (what Pattern::mapped holds, Pattern.hpp:60-103); false
+// if the read holds a symbol > 3 (matchUniqueImplementation.cpp:376-394)
+template <int W, class Row>
+__device__ __forceinline__ bool pack_read(const Row &row, uint32_t patl, uint64_t *O)
+{
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        uint64_t w = 0;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            const uint32_t bo = 32u * j + 4u * d;
+            if (bo < patl) {
+                uint32_t x = row.dword((int)bo, patl);
+                const uint32_t rem = patl - bo;
+                if (rem < 4) x &= (1u << (8 * rem)) - 1u;
+                if (x & 0xfcfcfcfcu) ok = false;
+                // bytes b0 b1 b2 b3 (2 bits each) -> b0<<6 | b1<<4 | b2<<2 | b3 in bits 24..31 of the product
+                w |= (uint64_t)(((x & 0x03030303u) * 0x40100401u) >> 24) << (56 - 8 * d);
+            }
+        }
+        O[j] = w;
+    }
+    return ok;
+}
+
+// seed halves (m0|m1), (m2|m3) of read[0..l) and of its reverse complement
+// (SignatureConstruction.hpp:347-410)
 template <int W>
+__device__ __forceinline__ void seed_halves(const uint64_t *O, uint32_t l, uint64_t &shi, uint64_t &slo, uint64_t &rhi, uint64_t &rlo)
+{
+    const uint32_t h = l >> 1; // 2..32 bases
+    const uint64_t hm = (h == 32) ? ~0ull : ((1ull << (2 * h)) - 1);
+    shi = O[0] >> (64 - 2 * h);
+    if (2 * h <= 32) slo = (O[0] >> (64 - 4 * h)) & hm;
+    else slo = ((h == 32) ? O[W > 1 ? 1 : 0] : (((O[0] << (2 * h)) | (O[W > 1 ? 1 : 0] >> (64 - 2 * h))) >> (64 - 2 * h)));
+    rhi = (rev2(slo) >> (64 - 2 * h)) ^ hm; // the revcomp of the second half comes first
+    rlo = (rev2(shi) >> (64 - 2 * h)) ^ hm;
+}
+
+// ComputeScore<...,true>::computeScore, ComputeScore.hpp:50-190: sequential FP64 sum in base order
+// starting at 1.0, cast to float once.  Ow = oriented read, tw = text aligned to the read, qrow = the
+// read's qualities as given (oriented here: base i of the reversed read has quality[patl-1-i],
+// Pattern.hpp:105-128); no qualities => 30 (Pattern.hpp:42-45).
+template <int W, class Row>
 __device__ __forceinline__ float score_location(const double *sLL, const uint64_t *Ow, const uint64_t *tw, uint32_t patl,
-                                                const uint8_t *__restrict__ qp)
+                                                const Row &qrow, bool has_q, uint32_t inv)
 {
     double raw = 1.0;
     // 16 bases per step in a real (not unrolled) loop: the adds are one dependent chain, and a fully
@@ -100,18 +173,20 @@ __device__ __forceinline__ float score_location(const double *sLL, const uint64_
         th[c] = (uint32_t)(tw[c >> 1] >> ((c & 1) ? 0 : 32));
         oh[c] = (uint32_t)(Ow[c >> 1] >> ((c & 1) ? 0 : 32));
     }
-    constexpr bool BATCHQ = (W <= 4); // short reads: all quality chunks in flight together (one round trip)
-    uint4 qv[BATCHQ ? NQ : 1];
-    if (BATCHQ) {
-#pragma unroll
-        for (int c = 0; c < NQ; ++c)
-            qv[c] = (16u * c < patl) ? *reinterpret_cast<const uint4 *>(qp + 16 * c) : make_uint4(0, 0, 0, 0);
-    }
     const uint32_t nchunk = (patl + 15) >> 4;
 #pragma unroll 1
     for (uint32_t c = 0; c < nchunk; ++c) {
-        const uint4 q4 = BATCHQ ? qv[0] : *reinterpret_cast<const uint4 *>(qp + 16 * c);
-        const uint32_t qa[4] = {q4.x, q4.y, q4.z, q4.w};
+        uint32_t qa[4] = {0x1e1e1e1eu, 0x1e1e1e1eu, 0x1e1e1e1eu, 0x1e1e1e1eu};
+        if (has_q) {
+            if (!inv) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) qa[i] = qrow.dword((int)(16 * c) + 4 * i, patl);
+            } else { // bytes [p-15, p] with p = patl-1-16c, last one first
+                const int p0 = (int)patl - 16 - (int)(16 * c);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) qa[i] = __builtin_bswap32(qrow.dword(p0 + 4 * (3 - i), patl));
+            }
+        }
         const uint32_t lim = min(16u, patl - 16u * c);
         const uint32_t tr = th[0], rr = oh[0];
 #pragma unroll
@@ -124,10 +199,7 @@ __device__ __forceinline__ float score_location(const double *sLL, const uint64_
             }
         }
 #pragma unroll
-        for (int i = 0; i + 1 < NQ; ++i) {
-            th[i] = th[i + 1]; oh[i] = oh[i + 1];
-            if (BATCHQ) qv[i] = qv[i + 1];
-        }
+        for (int i = 0; i + 1 < NQ; ++i) { th[i] = th[i + 1]; oh[i] = oh[i + 1]; }
     }
     return (float)raw;
 }
@@ -150,8 +222,8 @@ __device__ __forceinline__ void deliver(const MatchArgs &a, LaneState<W, SCORES,
 // distinct point (5-6 times per wave, mostly idle lanes).  Parked, the lanes score together at the end
 // of the read; the fold sees the same events in the same order.  A read that needs more slots
 // (repeat-rich) is handed to the repeat kernel, which scores in place.
-template <int W, bool SCORES, bool ALL>
-__device__ __forceinline__ void flush_pending(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL)
+template <int W, bool SCORES, bool ALL, class Row>
+__device__ __forceinline__ void flush_pending(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL, const Row &qrow)
 {
     float sc[NPEND] = {1.0f, 1.0f};
 #pragma unroll 1
@@ -181,7 +253,7 @@ __device__ __forceinline__ void flush_pending(const MatchArgs &a, LaneState<W, S
 #pragma unroll
             for (int i = 0; i < W; ++i) tw[i] = sh ? ((t[i] << sh) | (t[i + 1] >> (64 - sh))) : t[i];
         }
-        const float v = score_location<W>(sLL, Ow, tw, s.patl, a.b.qrows + s.r * (2ull * a.b.QS) + (uint64_t)inv * a.b.QS);
+        const float v = score_location<W>(sLL, Ow, tw, s.patl, qrow, a.b.qual != nullptr, inv);
         if (j) sc[1] = v; else sc[0] = v;
     }
 #pragma unroll 1
@@ -263,7 +335,7 @@ __device__ __forceinline__ void process_candidate(const MatchArgs &a, LaneState<
         if (total > a.totalkmax) return;
         float sc = 1.0f; // ComputeScore<...,false>, ComputeScore.hpp:31-45
         if (SCORES && !DEFER)
-            sc = score_location<W>(sLL, s.O, tw, s.patl, a.b.qrows + s.r * (2ull * a.b.QS) + (uint64_t)s.inv * a.b.QS);
+            sc = score_location<W>(sLL, s.O, tw, s.patl, GlobalRow{a.b.qual + s.o0}, a.b.qual != nullptr, (uint32_t)s.inv);
         if (SCORES && DEFER) { // the score is computed later: flush_pending
 #pragma unroll
             for (int j = 0; j < W; ++j) twl[j] = tw[j];
@@ -362,7 +434,7 @@ __device__ __forceinline__ bool scan_lists(const MatchArgs &a, LaneState<W, SCOR
                 cur[i] = x;
             }
         } else {
-            cur[i] = q_cur[i * 256 + threadIdx.x];
+            cur[i] = q_cur[i * 64];
         }
     }
     // 3. scan in list order, queue the survivors
@@ -398,8 +470,8 @@ __device__ __forceinline__ bool scan_lists(const MatchArgs &a, LaneState<W, SCOR
                         keep = __popc(((x >> 1) | x) & 0x55555555u) <= a.seedkmax;
                     }
                     if (keep) {
-                        q_pos[qn * 256 + threadIdx.x] = e.y;
-                        q_la[qn * 256 + threadIdx.x] = (uint8_t)(LA0 + i);
+                        q_pos[qn * 64] = e.y;
+                        q_la[qn * 64] = (uint8_t)(LA0 + i);
                         qn++;
                     }
                 }
@@ -411,7 +483,7 @@ __device__ __forceinline__ bool scan_lists(const MatchArgs &a, LaneState<W, SCOR
     }
     if (again) { // park the cursors in LDS; the continuation pass reloads them
 #pragma unroll
-        for (int i = 0; i < NL; ++i) q_cur[i * 256 + threadIdx.x] = cur[i];
+        for (int i = 0; i < NL; ++i) q_cur[i * 64] = cur[i];
     }
     return again;
 }
@@ -500,8 +572,8 @@ __device__ __forceinline__ void match_lists_fine(const MatchArgs &a, LaneState<W
                     // only be larger)
                     const uint32_t x = (e[u].x & pmask) ^ r;
                     if (__popc(((x >> 1) | x) & 0x55555555u) <= a.seedkmax) {
-                        q_pos[qn * 256 + threadIdx.x] = e[u].y;
-                        q_la[qn * 256 + threadIdx.x] = (uint8_t)(LA0 + li[u]);
+                        q_pos[qn * 64] = e[u].y;
+                        q_la[qn * 64] = (uint8_t)(LA0 + li[u]);
                         qn++;
                     }
                 }
@@ -509,7 +581,7 @@ __device__ __forceinline__ void match_lists_fine(const MatchArgs &a, LaneState<W
         }
         // 3. verify / score / fold in candidate order
         for (uint32_t k = 0; k < qn; ++k)
-            process_candidate<W, SCORES, ALL, DEFER>(a, s, sLL, q_pos[k * 256 + threadIdx.x], (int)q_la[k * 256 + threadIdx.x]);
+            process_candidate<W, SCORES, ALL, DEFER>(a, s, sLL, q_pos[k * 64], (int)q_la[k * 64]);
     }
 }
 
@@ -523,88 +595,177 @@ __device__ __forceinline__ void match_lists(const MatchArgs &a, LaneState<W, SCO
     bool again = scan_lists<W, SCORES, ALL, FINE, LA0, LA1, true>(a, s, q_pos, q_la, q_cur, donemask, qn);
     // 4. verify / score / fold in candidate order
     for (uint32_t k = 0; k < qn; ++k)
-        process_candidate<W, SCORES, ALL, DEFER>(a, s, sLL, q_pos[k * 256 + threadIdx.x], (int)q_la[k * 256 + threadIdx.x]);
+        process_candidate<W, SCORES, ALL, DEFER>(a, s, sLL, q_pos[k * 64], (int)q_la[k * 64]);
     while (again) {
         again = scan_lists<W, SCORES, ALL, FINE, LA0, LA1, false>(a, s, q_pos, q_la, q_cur, donemask, qn);
         for (uint32_t k = 0; k < qn; ++k)
-            process_candidate<W, SCORES, ALL, DEFER>(a, s, sLL, q_pos[k * 256 + threadIdx.x], (int)q_la[k * 256 + threadIdx.x]);
+            process_candidate<W, SCORES, ALL, DEFER>(a, s, sLL, q_pos[k * 64], (int)q_la[k * 64]);
     }
 }
 
-// REPEAT = false: the matcher proper, lane i of the grid takes read i.  With scores on it parks hits and scores
-// them at the end of the read (DEFER); a read that needs more than NPEND locations / PEND_EV events is left
-// untouched and its index appended to a.ovf_list.  REPEAT = true: the same matcher with in-place scoring over
-// the reads of a.ovf_list (grid-stride; the list length is read from device memory, no host round trip).
+// the wave copies bytes [src, src+nbytes) of the batch into its LDS region with 16-byte loads that are
+// aligned in global memory and never touch a byte outside the range; returns the LDS offset of src[0]
+__device__ __forceinline__ uint32_t stage_wave(uint8_t *stg, const uint8_t *src, uint64_t nbytes, uint32_t lane)
+{
+    const uintptr_t a0 = (uintptr_t)src, a1 = a0 + nbytes, c0 = a0 & ~(uintptr_t)15;
+    for (uintptr_t c = c0 + 16u * lane; c < a1; c += 16u * 64u) {
+        const uint32_t lo = STG_PAD + (uint32_t)(c - c0);
+        if (c >= a0 && c + 16 <= a1) {
+            *reinterpret_cast<uint4 *>(stg + lo) = *reinterpret_cast<const uint4 *>(c);
+        } else {
+            for (int b = 0; b < 16; ++b)
+                if (c + b >= a0 && c + b < a1) stg[lo + b] = *reinterpret_cast<const uint8_t *>(c + b);
+        }
+    }
+    return STG_PAD + (uint32_t)(a0 - c0);
+}
+// LDS traffic between the lanes of one wave: the hardware keeps a wave's LDS operations in order, the
+// compiler must too
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// both strands of one read (UniqueMatcher::match / AllMatcher::match, matchUniqueImplementation.cpp:396-500,
+// matchAllImplementation.cpp:261-355): s.O holds the read as given on entry, its reverse complement on exit
+template <int W, bool SCORES, bool ALL, bool FINE, bool DEFER>
+__device__ __forceinline__ void match_read(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL, uint32_t *q_pos,
+                                           uint8_t *q_la, uint32_t *q_cur)
+{
+    const uint32_t patl = s.patl;
+    s.nw = (patl + 31) >> 5;
+    s.lastmask = ~0ull << (64 - 2 * (patl - 32 * (s.nw - 1)));
+    s.eps = (float)(a.filter_mult * (double)patl); // RealOptions.hpp:74-77
+    s.p_n = s.p_nev = s.p_ev = 0; s.cslot = SLOT_NONE;
+    uint64_t rhi, rlo;
+    seed_halves<W>(s.O, a.l, s.shi, s.slo, rhi, rlo);
+    for (int inv = 0; inv < 2; ++inv) {
+        if (DEFER && s.p_n == PEND_OVF) break;
+        if (inv) { // transposed pattern, Pattern.hpp:105-128
+            uint64_t R[W];
+            revcomp_words<W>(s.O, R, patl);
+#pragma unroll
+            for (int j = 0; j < W; ++j) s.O[j] = R[j];
+            s.shi = rhi; s.slo = rlo;
+        }
+        s.inv = inv;
+        s.so = inv ? (patl - a.l) : 0u; // RestMatch::getMatchOffset, RestMatch.hpp:84-89
+        s.cpos = 0xffffffffu; s.ck = 0; s.cfrag = 0; s.cscore = 1.0f; s.cok = false;
+        s.crpos = 0xffffffffu; s.ckk = 0;
+        if (!ALL && !SCORES) {
+            // uni0s / uni0r early-out (matchUniqueImplementation.cpp:434-436, 470-472): lists 1..5 of a
+            // strand are skipped when list 0 left the record in this strand's state with 0 errors
+            match_lists<W, SCORES, ALL, FINE, DEFER, 0, 1>(a, s, sLL, q_pos, q_la, q_cur);
+            const unsigned st = (unsigned)(s.info >> ST_SHIFT), er = (unsigned)(s.info >> ER_SHIFT) & 15;
+            if (!(st == (unsigned)(inv ? ST_REVERSE : ST_STRAIGHT) && er == 0))
+                match_lists<W, SCORES, ALL, FINE, DEFER, 1, 6>(a, s, sLL, q_pos, q_la, q_cur);
+        } else {
+            match_lists<W, SCORES, ALL, FINE, DEFER, 0, 6>(a, s, sLL, q_pos, q_la, q_cur);
+        }
+    }
+}
+
+// REPEAT = false: the matcher proper, lane i of the grid takes read i of the batch.  A wave reads the bases
+// of its 64 reads -- one contiguous byte range of the caller's array -- through LDS, every lane packs its
+// own read into registers, matches both strands, and parks its hits (DEFER, scores on); then the wave reads
+// the qualities of its reads the same way and the lanes score and deliver together.  A read that needs more
+// than NPEND locations / PEND_EV events is left untouched and its index appended to a.ovf_list.
+// REPEAT = true: the same matcher with in-place scoring over the reads of a.ovf_list (grid-stride; the list
+// length is read from device memory, no host round trip); a lane fetches the bytes of its read itself.
 template <int W, bool SCORES, bool ALL, bool FINE, bool REPEAT>
 __global__ __launch_bounds__(256) void match_kernel(MatchArgs a)
 {
     constexpr bool DEFER = SCORES && !REPEAT;
     __shared__ double sLL[SCORES ? 1024 : 1];
-    __shared__ uint32_t q_pos[MQ * 256];
-    __shared__ uint8_t q_la[MQ * 256];
-    __shared__ uint32_t q_cur[6 * 256];
+    __shared__ __attribute__((aligned(16))) uint8_t smem[4 * STG_BYTES];
     if (SCORES) {
         for (int i = threadIdx.x; i < 1024; i += 256) sLL[i] = a.LL[i];
         __syncthreads();
     }
+    const uint32_t lane = threadIdx.x & 63;
+    uint8_t *stg = smem + (threadIdx.x >> 6) * STG_BYTES;
+    uint32_t *q_pos = reinterpret_cast<uint32_t *>(stg) + lane;
+    uint8_t *q_la = stg + MQ * 64 * 4 + lane;
+    uint32_t *q_cur = reinterpret_cast<uint32_t *>(stg + MQ * 64 * 5) + lane;
     LaneState<W, SCORES, ALL> s;
     s.cL = s.cP = s.cC = s.cS = s.cH = s.cV = 0;
+    s.info = 0; s.iscore = 0.f; s.o0 = 0;
     unsigned cR = 0;
-    const uint64_t n_items = REPEAT ? (uint64_t)*a.ovf_count : a.b.n_reads;
-    for (uint64_t it = (uint64_t)blockIdx.x * 256 + threadIdx.x; it < n_items; it += REPEAT ? (uint64_t)gridDim.x * 256 : n_items) {
-        const uint64_t r = REPEAT ? (uint64_t)a.ovf_list[it] : it;
-        const uint32_t patl = a.b.patl[r];
-        if (!patl) continue;
-        const unsigned c0[6] = {s.cL, s.cP, s.cC, s.cS, s.cH, s.cV};
-        s.r = r; s.patl = patl;
-        s.nw = (patl + 31) >> 5;
-        s.lastmask = ~0ull << (64 - 2 * (patl - 32 * (s.nw - 1)));
-        s.eps = (float)(a.filter_mult * (double)patl); // RealOptions.hpp:74-77
-        s.info = 0; s.iscore = 0.f;
-        s.p_n = s.p_nev = s.p_ev = 0; s.cslot = SLOT_NONE;
-        if (!ALL) {
-            s.info = a.info[r];
-            if (SCORES) s.iscore = a.score[r];
+    const uint64_t n = a.b.n_reads;
+
+    if (!REPEAT) {
+        const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+        const uint64_t rc = r < n ? r : n; // lanes behind the batch: an empty range at its end
+        const uint64_t o0 = a.b.off ? a.b.off[rc] : rc * (uint64_t)a.b.upatl;
+        const uint64_t o1 = r < n ? (a.b.off ? a.b.off[r + 1] : o0 + a.b.upatl) : o0;
+        const uint32_t patl = (uint32_t)(o1 - o0);
+        const uint32_t GL = a.b.gl; // reads the wave stages at a time: GL * max_patl fits its LDS region
+        // ---- bases: global -> LDS -> registers
+        bool elig = false;
+        for (uint32_t g = 0; g < 64; g += GL) {
+            const uint64_t gb = __shfl(o0, (int)g), ge = __shfl(o1, (int)(g + GL - 1));
+            wave_lds_sync();
+            const uint32_t l0 = stage_wave(stg, a.b.bases + gb, ge - gb, lane);
+            wave_lds_sync();
+            if (lane >= g && lane < g + GL && patl >= a.l && patl <= 32u * W) // matchUniqueImplementation.cpp:376-394
+                elig = pack_read<W>(LdsRow{stg, l0 + (uint32_t)(o0 - gb)}, patl, s.O);
         }
-        for (int inv = 0; inv < 2; ++inv) {
-            if (DEFER && s.p_n == PEND_OVF) break;
-            const uint64_t *wp = a.b.words + r * (2 * W) + inv * W;
-#pragma unroll
-            for (int j = 0; j < W; j += 2) {
-                if (j + 1 < W) { const U64x2 p2 = load2(wp + j); s.O[j] = p2.a; s.O[j + 1] = p2.b; }
-                else s.O[j] = wp[j];
+        wave_lds_sync();
+        // ---- match
+        s.r = r; s.patl = patl; s.p_n = 0;
+        if (elig) {
+            if (!ALL) {
+                s.info = a.info[r];
+                if (SCORES) s.iscore = a.score[r];
             }
-            {
-                const U64x2 sd = load2(a.b.seeds + r * 4 + inv * 2);
-                s.shi = sd.a; s.slo = sd.b;
-            }
-            s.inv = inv;
-            s.so = inv ? (patl - a.l) : 0u; // RestMatch::getMatchOffset, RestMatch.hpp:84-89
-            s.cpos = 0xffffffffu; s.ck = 0; s.cfrag = 0; s.cscore = 1.0f; s.cok = false;
-            s.crpos = 0xffffffffu; s.ckk = 0;
-            if (!ALL && !SCORES) {
-                // uni0s / uni0r early-out (matchUniqueImplementation.cpp:434-436, 470-472): lists 1..5 of a
-                // strand are skipped when list 0 left the record in this strand's state with 0 errors
-                match_lists<W, SCORES, ALL, FINE, DEFER, 0, 1>(a, s, sLL, q_pos, q_la, q_cur);
-                const unsigned st = (unsigned)(s.info >> ST_SHIFT), er = (unsigned)(s.info >> ER_SHIFT) & 15;
-                if (!(st == (unsigned)(inv ? ST_REVERSE : ST_STRAIGHT) && er == 0))
-                    match_lists<W, SCORES, ALL, FINE, DEFER, 1, 6>(a, s, sLL, q_pos, q_la, q_cur);
-            } else {
-                match_lists<W, SCORES, ALL, FINE, DEFER, 0, 6>(a, s, sLL, q_pos, q_la, q_cur);
-            }
+            match_read<W, SCORES, ALL, FINE, DEFER>(a, s, sLL, q_pos, q_la, q_cur);
         }
-        if (DEFER && s.p_n == PEND_OVF) {
-            // nothing of this read has been delivered or counted: the repeat kernel does it all
+        const bool ovf = DEFER && elig && s.p_n == PEND_OVF;
+        if (ovf) {
+            // nothing of this read has been delivered: the repeat kernel does it all and counts it
             const unsigned long long slot = wave_append_slot(a.ovf_count);
             a.ovf_list[slot] = (uint32_t)r;
-            s.cL = c0[0]; s.cP = c0[1]; s.cC = c0[2]; s.cS = c0[3]; s.cH = c0[4]; s.cV = c0[5];
-            continue;
+            s.cL = s.cP = s.cC = s.cS = s.cH = s.cV = 0;
         }
-        cR++;
-        if (DEFER) flush_pending<W, SCORES, ALL>(a, s, sLL); // the lanes of the wave score together
-        if (!ALL) {
-            a.info[r] = s.info;
-            if (SCORES) a.score[r] = s.iscore;
+        // ---- qualities: global -> LDS; score the parked hits and deliver them
+        if (DEFER) {
+            for (uint32_t g = 0; g < 64; g += GL) {
+                const uint64_t gb = __shfl(o0, (int)g), ge = __shfl(o1, (int)(g + GL - 1));
+                const bool mine = lane >= g && lane < g + GL && elig && !ovf && s.p_n;
+                if (!__any(mine)) continue;
+                uint32_t l0 = 0;
+                wave_lds_sync();
+                if (a.b.qual) l0 = stage_wave(stg, a.b.qual + gb, ge - gb, lane);
+                wave_lds_sync();
+                if (mine) flush_pending<W, SCORES, ALL>(a, s, sLL, LdsRow{stg, l0 + (uint32_t)(o0 - gb)});
+            }
+        }
+        if (elig && !ovf) {
+            cR = 1;
+            if (!ALL) {
+                a.info[r] = s.info;
+                if (SCORES) a.score[r] = s.iscore;
+            }
+        }
+    } else {
+        const uint64_t n_items = (uint64_t)*a.ovf_count;
+        for (uint64_t it = (uint64_t)blockIdx.x * 256 + threadIdx.x; it < n_items; it += (uint64_t)gridDim.x * 256) {
+            const uint64_t r = a.ovf_list[it];
+            const uint64_t o0 = a.b.off ? a.b.off[r] : r * (uint64_t)a.b.upatl;
+            const uint32_t patl = a.b.off ? (uint32_t)(a.b.off[r + 1] - o0) : a.b.upatl;
+            s.r = r; s.o0 = o0; s.patl = patl;
+            pack_read<W>(GlobalRow{a.b.bases + o0}, patl, s.O); // (eligible: the matcher handed it over)
+            if (!ALL) {
+                s.info = a.info[r];
+                if (SCORES) s.iscore = a.score[r];
+            }
+            match_read<W, SCORES, ALL, FINE, DEFER>(a, s, sLL, q_pos, q_la, q_cur);
+            cR++;
+            if (!ALL) {
+                a.info[r] = s.info;
+                if (SCORES) a.score[r] = s.iscore;
+            }
         }
     }
 
@@ -678,6 +839,12 @@ int rh_launch_match(real_hip_ctx *ctx, const MatchArgs &args, bool all)
     MatchArgs a = args;
     const bool sc = ctx->prm.scores != 0;
     int rc;
+    { // reads a wave stages at a time: their bytes (+ alignment skew, pad, one dword of over-read) fit its LDS region
+        const uint32_t maxlen = a.b.off ? 32u * a.b.W : a.b.upatl;
+        uint32_t gl = 64;
+        while (gl > 1 && (uint64_t)gl * maxlen + STG_PAD + 16 + 16 > STG_BYTES) gl >>= 1;
+        a.b.gl = gl;
+    }
     if (sc) { // hand-over list of the reads the matcher leaves to the repeat kernel
         if ((rc = rh_reserve(ctx, ctx->ovf_list, a.b.n_reads * 4))) return rc;
         if ((rc = rh_reserve(ctx, ctx->ovf_count, 8))) return rc;

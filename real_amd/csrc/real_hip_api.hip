@@ -172,16 +172,7 @@ extern "C" int real_hip_create(real_hip_ctx **out, const real_hip_params *p)
     do {
         if (hipSetDevice(c->device) != hipSuccess) { rc = REAL_HIP_E_DEVICE; break; }
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = REAL_HIP_E_DEVICE; break; }
-        if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { rc = REAL_HIP_E_DEVICE; break; }
         if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { rc = REAL_HIP_E_DEVICE; break; }
-        {
-            bool ok = true;
-            for (int i = 0; i < 2; ++i)
-                ok = ok && hipEventCreateWithFlags(&c->ev_packed[i], hipEventDisableTiming) == hipSuccess &&
-                     hipEventCreateWithFlags(&c->ev_matched[i], hipEventDisableTiming) == hipSuccess;
-            ok = ok && hipEventCreateWithFlags(&c->ev_staged, hipEventDisableTiming) == hipSuccess;
-            if (!ok) { rc = REAL_HIP_E_DEVICE; break; }
-        }
         if ((rc = rh_reserve(c, c->LL, 1024 * sizeof(double)))) break;
         if ((rc = rh_reserve(c, c->counters, (size_t)(RH_CSTRIPES + 1) * 16 * sizeof(uint64_t)))) break;
         if (hipMemcpy(c->LL.p, p->LL, 1024 * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { rc = REAL_HIP_E_DEVICE; break; }
@@ -198,16 +189,12 @@ extern "C" void real_hip_destroy(real_hip_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->text, &c->wild, &c->frag, &c->LL, &c->counters, &c->s_bases, &c->s_qual, &c->s_off, &c->s_info,
-                     &c->s_score, &c->words, &c->seeds, &c->qrows, &c->patl, &c->maxpatl, &c->ovf_list, &c->ovf_count, &c->raw, &c->raw_count, &c->keys_a,
+                     &c->s_score, &c->maxpatl, &c->ovf_list, &c->ovf_count, &c->raw, &c->raw_count, &c->keys_a,
                      &c->keys_b, &c->vals_a, &c->vals_b, &c->sort_tmp, &c->hit_off, &c->s_hits};
     for (DevBuf *b : all) rh_release(*b);
     for (int k = 0; k < 6; ++k) { rh_release(c->ent[k]); rh_release(c->bkt[k]); }
-    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     rh_time_resolve(c);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
-    for (int i = 0; i < 2; ++i) { if (c->ev_packed[i]) (void)hipEventDestroy(c->ev_packed[i]); if (c->ev_matched[i]) (void)hipEventDestroy(c->ev_matched[i]); }
-    if (c->ev_staged) (void)hipEventDestroy(c->ev_staged);
-    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -380,7 +367,7 @@ extern "C" int real_hip_index_export(real_hip_ctx *ctx, int list, void *sign, ui
 struct Staged {
     const uint8_t *bases = nullptr, *qual = nullptr;
     const uint64_t *off = nullptr;
-    uint32_t upatl = 0, maxpatl = 0, W = 0, QS = 0;
+    uint32_t upatl = 0, maxpatl = 0, W = 0;
 };
 
 static int stage_batch(real_hip_ctx *ctx, const real_hip_batch *b, Staged &s)
@@ -430,32 +417,10 @@ static int stage_batch(real_hip_ctx *ctx, const real_hip_batch *b, Staged &s)
     if (s.maxpatl > REAL_HIP_MAX_PATL) return rh_fail(ctx, REAL_HIP_E_UNSUPPORTED, "read longer than REAL_HIP_MAX_PATL", hipSuccess);
     s.W = (s.maxpatl + 31) / 32;
     if (s.W < 1) s.W = 1;
-    s.QS = 32 * s.W;
     return REAL_HIP_OK;
 }
 
-// packed form of `cap` reads (x `nbuf` buffers)
-static int reserve_packed(real_hip_ctx *ctx, const Staged &s, uint64_t cap, int nbuf)
-{
-    int rc;
-    if ((rc = rh_reserve(ctx, ctx->words, (size_t)nbuf * cap * 2 * s.W * 8))) return rc;
-    if ((rc = rh_reserve(ctx, ctx->seeds, (size_t)nbuf * cap * 4 * 8))) return rc;
-    if ((rc = rh_reserve(ctx, ctx->patl, (size_t)nbuf * cap * 4))) return rc;
-    if (ctx->prm.scores && (rc = rh_reserve(ctx, ctx->qrows, (size_t)nbuf * cap * 2 * (size_t)s.QS))) return rc;
-    return REAL_HIP_OK;
-}
-
-static PackOut packed_at(real_hip_ctx *ctx, const Staged &s, uint64_t first_read)
-{
-    PackOut o;
-    o.words = (uint64_t *)ctx->words.p + first_read * 2 * s.W;
-    o.seeds = (uint64_t *)ctx->seeds.p + first_read * 4;
-    o.patl = (uint32_t *)ctx->patl.p + first_read;
-    o.qrows = ctx->qrows.p ? (uint8_t *)ctx->qrows.p + first_read * 2 * (size_t)s.QS : nullptr;
-    return o;
-}
-
-static void fill_args(real_hip_ctx *ctx, const Staged &s, uint64_t n, const PackOut &pk, MatchArgs &a)
+static void fill_args(real_hip_ctx *ctx, const Staged &s, uint64_t n, MatchArgs &a)
 {
     memset(&a, 0, sizeof a);
     a.t.text = (const uint64_t *)ctx->text.p; a.t.wild = (const uint64_t *)ctx->wild.p;
@@ -466,8 +431,8 @@ static void fill_args(real_hip_ctx *ctx, const Staged &s, uint64_t n, const Pack
     a.ix.n = ctx->n_entries; a.ix.pb = pb;
     rh_index_geometry(l, pb, &a.ix.pshift, &a.ix.fshift, &a.ix.fbits, &a.ix.pbits);
     a.ix.fine = ctx->fine ? 1u : 0u;
-    a.b.words = pk.words; a.b.seeds = pk.seeds; a.b.qrows = pk.qrows; a.b.patl = pk.patl;
-    a.b.n_reads = n; a.b.W = s.W; a.b.QS = s.QS;
+    a.b.bases = s.bases; a.b.qual = ctx->prm.scores ? s.qual : nullptr; a.b.off = s.off;
+    a.b.n_reads = n; a.b.upatl = s.upatl; a.b.W = s.W;
     a.LL = (const double *)ctx->LL.p;
     a.counters = (unsigned long long *)ctx->counters.p;
     a.filter_mult = ctx->prm.filter_mult;
@@ -496,38 +461,14 @@ extern "C" int real_hip_match_unique(real_hip_ctx *ctx, const real_hip_batch *b,
             d_score = (float *)ctx->s_score.p;
         }
     }
-    // Chunked two-stream pipeline: the packer (HBM streaming bound) of chunk c+1 runs on its own stream
-    // beside the matcher (random-request bound) of chunk c; two packed buffers, events order the reuse.
-    // (default: one chunk -- measured on MI355X the overlap buys nothing, both kernels load the same memory
-    //  system; REAL_HIP_CHUNK_READS turns the pipeline on, it also halves the packed-buffer footprint)
-    uint64_t CH = n;
-    if (const char *e = getenv("REAL_HIP_CHUNK_READS")) { uint64_t v = strtoull(e, nullptr, 10); if (v >= 1024) CH = v; }
-    if (CH > n) CH = n;
-    const uint64_t nchunks = (n + CH - 1) / CH;
-    if ((rc = reserve_packed(ctx, s, CH, nchunks > 1 ? 2 : 1))) return rc;
-    RH_HIP(ctx, hipEventRecord(ctx->ev_staged, ctx->stream));      // host->device staging copies (if any) precede the packer
-    RH_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_staged, 0));
-    for (uint64_t c = 0; c < nchunks; ++c) {
-        const uint64_t r0 = c * CH, m = (r0 + CH <= n) ? CH : (n - r0);
-        const int bsel = (int)(c & 1);
-        const PackOut pk = packed_at(ctx, s, (uint64_t)bsel * CH);
-        if (c >= 2) RH_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_matched[bsel], 0)); // buffer free again
-        const uint8_t *cb = s.off ? s.bases : s.bases + r0 * (uint64_t)s.upatl;
-        const uint8_t *cq = s.qual ? (s.off ? s.qual : s.qual + r0 * (uint64_t)s.upatl) : nullptr;
-        if ((rc = rh_launch_pack(ctx, ctx->stream2, cb, cq, s.off ? s.off + r0 : nullptr, s.upatl, m, s.W, s.QS, pk))) return rc;
-        RH_HIP(ctx, hipEventRecord(ctx->ev_packed[bsel], ctx->stream2));
-        RH_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_packed[bsel], 0));
-        MatchArgs a;
-        fill_args(ctx, s, m, pk, a);
-        a.info = d_info + r0; a.score = d_score ? d_score + r0 : nullptr;
-        if ((rc = rh_launch_match(ctx, a, false))) return rc;
-        RH_HIP(ctx, hipEventRecord(ctx->ev_matched[bsel], ctx->stream));
-    }
+    MatchArgs a;
+    fill_args(ctx, s, n, a);
+    a.info = d_info; a.score = d_score;
+    if ((rc = rh_launch_match(ctx, a, false))) return rc;
     if (!b->on_device) {
         RH_HIP(ctx, hipMemcpyAsync(info, d_info, n * 8, hipMemcpyDeviceToHost, ctx->stream));
         if (sc) RH_HIP(ctx, hipMemcpyAsync(score, d_score, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     }
-    RH_HIP(ctx, hipStreamSynchronize(ctx->stream2));
     RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     rh_time_resolve(ctx);
     return REAL_HIP_OK;
@@ -548,11 +489,8 @@ extern "C" int real_hip_match_all(real_hip_ctx *ctx, const real_hip_batch *b, re
     if ((rc = rh_reserve(ctx, ctx->raw, (cap ? cap : 1) * sizeof(uint4)))) return rc;
     unsigned long long n_raw = 0;
     if (n) {
-        if ((rc = reserve_packed(ctx, s, n, 1))) return rc;
-        const PackOut pk = packed_at(ctx, s, 0);
-        if ((rc = rh_launch_pack(ctx, ctx->stream, s.bases, s.qual, s.off, s.upatl, n, s.W, s.QS, pk))) return rc;
         MatchArgs a;
-        fill_args(ctx, s, n, pk, a);
+        fill_args(ctx, s, n, a);
         a.raw = (uint4 *)ctx->raw.p; a.raw_count = (unsigned long long *)ctx->raw_count.p; a.raw_cap = cap;
         if ((rc = rh_launch_match(ctx, a, true))) return rc;
         RH_HIP(ctx, hipMemcpyAsync(&n_raw, ctx->raw_count.p, 8, hipMemcpyDeviceToHost, ctx->stream));

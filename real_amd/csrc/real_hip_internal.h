@@ -58,13 +58,15 @@ static inline void rh_index_geometry(uint32_t l, uint32_t pb, uint32_t *pshift, 
     }
 }
 
+// a batch of reads as the caller holds it (real_hip_batch): the matcher reads these arrays itself
 struct DevBatch {
-    const uint64_t *words; // [n_reads][2][W]   oriented reads, 32 bases / word, MSB first
-    const uint64_t *seeds; // [n_reads][2][2]   seed halves (s0, s5) of each orientation
-    const uint8_t  *qrows; // [n_reads][2][QS]  oriented quality rows (16-byte aligned)
-    const uint32_t *patl;  // [n_reads]         0 = skipped read
+    const uint8_t  *bases; // concatenated mapped symbols 0..4
+    const uint8_t  *qual;  // concatenated qualities 0..63, nullptr => 30
+    const uint64_t *off;   // n_reads + 1 start offsets, nullptr => uniform length upatl
     uint64_t n_reads;
-    uint32_t W, QS;
+    uint32_t upatl;
+    uint32_t W;            // 64-bit words per oriented read = ceil(max read length / 32)
+    uint32_t gl;           // reads a wave stages through its LDS region at a time (power of two <= 64)
 };
 
 struct MatchArgs {
@@ -95,9 +97,7 @@ struct DevBuf {
 struct real_hip_ctx {
     real_hip_params prm;
     int device = 0;
-    hipStream_t stream = nullptr;  // matcher (and everything else)
-    hipStream_t stream2 = nullptr; // packer of the next chunk, overlapped with the matcher
-    hipEvent_t ev_packed[2] = {nullptr, nullptr}, ev_matched[2] = {nullptr, nullptr}, ev_staged = nullptr;
+    hipStream_t stream = nullptr;
     std::string last_error;
 
     // text
@@ -117,9 +117,9 @@ struct real_hip_ctx {
     // tables / counters
     DevBuf LL, counters;
 
-    // batch staging + packed form
+    // batch staging (host batches), hand-over list of the repeat kernel
     DevBuf s_bases, s_qual, s_off, s_info, s_score;
-    DevBuf words, seeds, qrows, patl, maxpatl, ovf_list, ovf_count;
+    DevBuf maxpatl, ovf_list, ovf_count;
     // matchAll workspace
     DevBuf raw, raw_count, keys_a, keys_b, vals_a, vals_b, sort_tmp, hit_off, s_hits;
 
@@ -152,10 +152,6 @@ struct RhTimer { // HIP events on the ctx stream around a group of launches
 };
 
 // ---- kernels launchers (match_kernels.hip) -----------------------------------
-struct PackOut { uint64_t *words; uint64_t *seeds; uint8_t *qrows; uint32_t *patl; };
-int rh_launch_pack(real_hip_ctx *ctx, hipStream_t st, const uint8_t *d_bases, const uint8_t *d_qual,
-                   const uint64_t *d_off, uint32_t uniform_patl, uint64_t n_reads,
-                   uint32_t W, uint32_t QS, const PackOut &out);
 int rh_launch_match(real_hip_ctx *ctx, const MatchArgs &a, bool all);
 // asynchronous kernel timing (no host synchronisation at the launch site)
 void rh_time_begin(real_hip_ctx *ctx, hipStream_t st, int which);

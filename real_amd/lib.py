@@ -24,7 +24,7 @@ REAL_HIP_E_STATE = -5
 REAL_HIP_E_UNSUPPORTED = -6
 REAL_HIP_MAX_PATL = 256
 
-K_PACK, K_MATCH_UNIQUE, K_MATCH_ALL, K_ALL_SORT, K_INDEX, K_MATCH_REPEAT = range(6)
+K_MATCH_UNIQUE, K_MATCH_ALL, K_ALL_SORT, K_INDEX, K_MATCH_REPEAT = range(5)
 
 # every symbol include/real_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
