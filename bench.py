@@ -222,7 +222,7 @@ def main():
                           "reads_per_s": n * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "hits_per_step": nh,
                           "genome_bp": G, "reads": n, "read_len": args.patl, "seedl": args.seedl, "totalk": args.totalk,
                           "kernel_ms": {nm: m.kernel_time(i)[0] / max(m.kernel_time(i)[1], 1)
-                                        for i, nm in enumerate(["pack", "match_unique", "match_all", "all_sort", "index"])}}), flush=True)
+                                        for i, nm in enumerate(["match_unique", "match_all", "all_sort", "index", "match_repeat"])}}), flush=True)
         return
 
     def step():

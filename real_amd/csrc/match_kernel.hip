@@ -674,7 +674,7 @@ __device__ __forceinline__ void match_read(const MatchArgs &a, LaneState<W, SCOR
 // REPEAT = true: the same matcher with in-place scoring over the reads of a.ovf_list (grid-stride; the list
 // length is read from device memory, no host round trip); a lane fetches the bytes of its read itself.
 template <int W, bool SCORES, bool ALL, bool FINE, bool REPEAT>
-__global__ __launch_bounds__(256) void match_kernel(MatchArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 : 2))) void match_kernel(MatchArgs a)
 {
     constexpr bool DEFER = SCORES && !REPEAT;
     __shared__ double sLL[SCORES ? 1024 : 1];
