@@ -92,10 +92,11 @@ uint32_t rh_choose_prefix_bits(const real_hip_ctx *ctx, uint64_t n_entries)
         uint32_t lg = 0;
         while ((1ull << (lg + 1)) <= (n_entries ? n_entries : 1)) lg++;
         if (l <= 32 && lg >= 27) {
-            // large index, 32-bit signatures: prefix = all signature bits but two ("fine" tables: the bucket
-            // table also holds the sizes of the (at most four) key groups of a bucket, so a lookup lands on
-            // the reference's equal range without scanning); 8 B x 2^(l-2) per list
-            pb = l - 2;
+            // large index, 32-bit signatures: prefix = all signature bits but three ("fine" tables: the bucket
+            // table also holds size and partner digest of the (at most eight) key groups of a bucket, so a
+            // lookup lands on the reference's equal range without scanning, and on nothing at all when the
+            // range is one chance entry); 16 B x 2^(l-3) per list
+            pb = l - 3;
         } else {
             // mean bucket of 2..4 entries (the first two entries of every bucket are prefetched together)
             pb = lg > 1 ? lg - 1 : 1;
@@ -155,23 +156,40 @@ __global__ void entries_kernel(const K *__restrict__ sign, const uint32_t *__res
         for (uint64_t q = (uint64_t)p + 1; q <= nbuckets; ++q) bkt[q] = (uint32_t)n;
 }
 
-// fine bucket table: {start, sizes of the four key groups (one byte each)}.  255 means "255 or more":
-// the matcher then finds that group's bounds by binary search inside the bucket.
+// fine bucket table: uint4 {start, 96 bits = 8 x {size:4, digest:8}} per bucket, field g = key group g
+// (= signature value g of the bucket).  size 15 means "15 or more": the matcher then finds that group's
+// bounds by binary search inside the bucket.  digest = the leading (at most 8) partner-signature bits of
+// the group's first entry: for a group of one entry the matcher evaluates the seed popcount filter on
+// those symbols first and, if it already fails, never touches the entry (a whole 128-byte line saved
+// for 3/4 of the chance candidates).
 __global__ void fine_table_kernel(const uint32_t *__restrict__ bkt, const uint2 *__restrict__ ent, uint64_t nbuckets,
-                                  uint32_t pbits, uint2 *__restrict__ out)
+                                  uint32_t pbits, uint32_t fbits, uint4 *__restrict__ out)
 {
     uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p > nbuckets) return;
     const uint32_t start = bkt[p];
-    uint32_t g[4] = {0, 0, 0, 0};
+    uint32_t fld[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (p < nbuckets) {
         const uint32_t end = bkt[p + 1];
+        const uint32_t dbits = pbits < 8 ? pbits : 8, gmask = (1u << fbits) - 1, pmask = pbits ? ((1u << pbits) - 1) : 0u;
         for (uint32_t j = start; j < end; ++j) {
-            const uint32_t k = (ent[j].x >> pbits) & 3;
-            if (g[k] < 255) g[k]++;
+            const uint32_t x = ent[j].x;
+            const uint32_t k = (x >> pbits) & gmask;
+            uint32_t f = 0;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) if (k == (uint32_t)g) f = fld[g];
+            if ((f & 15u) == 0) f = (((x & pmask) >> (pbits - dbits)) << 4) | 1u;
+            else if ((f & 15u) < RH_FINE_SAT) f++;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) if (k == (uint32_t)g) fld[g] = f;
         }
     }
-    out[p] = make_uint2(start, g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24));
+    uint64_t lo = 0;
+#pragma unroll
+    for (int g = 0; g < 5; ++g) lo |= (uint64_t)fld[g] << (12 * g);
+    lo |= (uint64_t)(fld[5] & 15u) << 60;
+    const uint32_t hi = (fld[5] >> 4) | (fld[6] << 8) | (fld[7] << 20);
+    out[p] = make_uint4(start, (uint32_t)lo, (uint32_t)(lo >> 32), hi);
 }
 
 int rh_index_from_sorted(real_hip_ctx *ctx, int list, const void *d_sign, const uint32_t *d_pos, uint64_t n,
@@ -183,12 +201,12 @@ int rh_index_from_sorted(real_hip_ctx *ctx, int list, const void *d_sign, const 
     const uint32_t nb = 1u << pb;
     int rc = rh_reserve(ctx, ctx->ent[list], (n ? n : 1) * sizeof(uint2));
     if (rc) return rc;
-    if (ctx->fine) rh_release(ctx->bkt[list]); // holds a uint2 table from the previous block
+    if (ctx->fine) rh_release(ctx->bkt[list]); // holds a uint4 table from the previous block
     rc = rh_reserve(ctx, ctx->bkt[list], ((size_t)nb + 1) * 4);
     if (rc) return rc;
     if (!n) {
-        if (ctx->fine && (rc = rh_reserve(ctx, ctx->bkt[list], ((size_t)nb + 1) * 8))) return rc;
-        RH_HIP(ctx, hipMemsetAsync(ctx->bkt[list].p, 0, ((size_t)nb + 1) * (ctx->fine ? 8 : 4), ctx->stream));
+        if (ctx->fine && (rc = rh_reserve(ctx, ctx->bkt[list], ((size_t)nb + 1) * 16))) return rc;
+        RH_HIP(ctx, hipMemsetAsync(ctx->bkt[list].p, 0, ((size_t)nb + 1) * (ctx->fine ? 16 : 4), ctx->stream));
         return REAL_HIP_OK;
     }
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
@@ -202,9 +220,10 @@ int rh_index_from_sorted(real_hip_ctx *ctx, int list, const void *d_sign, const 
     RH_HIP(ctx, hipGetLastError());
     if (ctx->fine) {
         DevBuf fine_tab;
-        if ((rc = rh_reserve(ctx, fine_tab, ((size_t)nb + 1) * sizeof(uint2)))) return rc;
+        if ((rc = rh_reserve(ctx, fine_tab, ((size_t)nb + 1) * sizeof(uint4)))) return rc;
         hipLaunchKernelGGL(fine_table_kernel, dim3((unsigned)(((uint64_t)nb + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
-                           (const uint32_t *)ctx->bkt[list].p, (const uint2 *)ctx->ent[list].p, (uint64_t)nb, pbits, (uint2 *)fine_tab.p);
+                           (const uint32_t *)ctx->bkt[list].p, (const uint2 *)ctx->ent[list].p, (uint64_t)nb, pbits, fbits,
+                           (uint4 *)fine_tab.p);
         RH_HIP(ctx, hipGetLastError());
         RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
         rh_release(ctx->bkt[list]);
@@ -319,7 +338,7 @@ int rh_index_build_device(real_hip_ctx *ctx, uint64_t first_window, uint64_t max
     }
     ctx->n_entries = cnt;
     ctx->pb = rh_choose_prefix_bits(ctx, cnt);
-    ctx->fine = (l >= ctx->pb) && (l - ctx->pb) >= 1 && (l - ctx->pb) <= 2;
+    ctx->fine = rh_is_fine(l, ctx->pb);
     for (int k = 0; k < 6; ++k) {
         rc = (l <= 32) ? sort_list<uint32_t>(ctx, k, d_wpos, cnt) : sort_list<uint64_t>(ctx, k, d_wpos, cnt);
         if (rc) return rc;

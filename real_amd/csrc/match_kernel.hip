@@ -488,11 +488,12 @@ __device__ __forceinline__ bool scan_lists(const MatchArgs &a, LaneState<W, SCOR
     return again;
 }
 
-// Fine tables (32-bit signatures, large index): the bucket table entry {start, sizes of the four key
-// groups} of a prefix gives the reference's equal range of every list directly.  The lane enumerates the
-// equal ranges of all lists in list order -- the canonical candidate order -- four entries per round trip,
-// applies the partner filter and queues the survivors; a full queue is drained and refilled (the only
-// state across a drain is the enumeration offset).
+// Fine tables (32-bit signatures, large index): the 16-byte bucket table entry {start, size and partner digest
+// of each of the (at most eight) key groups} of a prefix gives the reference's equal range of every list
+// directly, and for a range of one entry enough of its partner signature to reject most chance candidates
+// without reading them.  The lane enumerates the equal ranges of all lists in list order -- the canonical
+// candidate order -- eight entries per round trip, applies the partner filter and queues the survivors; a
+// full queue is drained and refilled (the only state across a drain is the enumeration offset).
 template <int W, bool SCORES, bool ALL, bool DEFER, int LA0, int LA1>
 __device__ __forceinline__ void match_lists_fine(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL,
                                                  uint32_t *q_pos, uint8_t *q_la)
@@ -502,11 +503,12 @@ __device__ __forceinline__ void match_lists_fine(const MatchArgs &a, LaneState<W
     const uint64_t m[4] = {s.shi >> bb, s.shi & mb, s.slo >> bb, s.slo & mb};
     constexpr int NL = LA1 - LA0;
     const uint32_t pbits = a.ix.pbits, pmask = (1u << pbits) - 1, G = 1u << a.ix.fbits;
-    uint32_t lo[NL], cum[NL], rp[NL], total = 0;
+    uint32_t lo[NL], cum[NL], rp[NL], total = 0, counted = 0;
+    const uint32_t dbits = pbits < 8 ? pbits : 8;
     {
-        uint2 t[NL];
+        uint4 t[NL];
         uint32_t f[NL], prefix[NL];
-        // 1. one 8-byte table entry per list, all in flight together
+        // 1. one 16-byte table entry per list, all in flight together
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
             const int la = LA0 + i;
@@ -517,30 +519,47 @@ __device__ __forceinline__ void match_lists_fine(const MatchArgs &a, LaneState<W
             const int lb = 5 - la; // partner signature s_b = signature of list 5-la
             const int xb = (lb < 3) ? 0 : (lb < 5) ? 1 : 2, xd = (lb == 0) ? 1 : (lb == 1 || lb == 3) ? 2 : 3;
             rp[i] = (uint32_t)(((m[xb] << bb) | m[xd]) >> (a.l - pbits));
-            t[i] = reinterpret_cast<const uint2 *>(a.ix.bkt[la])[prefix[i]];
+            t[i] = reinterpret_cast<const uint4 *>(a.ix.bkt[la])[prefix[i]];
         }
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
-            const uint32_t g0 = t[i].y & 255u, g1 = (t[i].y >> 8) & 255u, g2 = (t[i].y >> 16) & 255u, g3 = t[i].y >> 24;
-            const uint32_t fi = f[i];
-            uint32_t off = (fi > 0 ? g0 : 0u) + (fi > 1 ? g1 : 0u) + (fi > 2 ? g2 : 0u);
-            uint32_t sz = fi == 0 ? g0 : fi == 1 ? g1 : fi == 2 ? g2 : g3;
-            const bool sat = (g0 == 255u) || (fi > 0 && g1 == 255u) || (fi > 1 && g2 == 255u) || (fi > 2 && g3 == 255u);
+            // the entry's 96 bits = 8 fields {size:4, digest:8}, field g = key group g of the bucket
+            const uint64_t flo = (uint64_t)t[i].y | ((uint64_t)t[i].z << 32);
+            const uint32_t fhi = t[i].w, fi = f[i];
+            uint32_t off = 0, mine = 0;
+            bool sat = false;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const uint32_t fld = (g < 5) ? ((uint32_t)(flo >> (12 * g)) & 0xfffu)
+                                   : (g == 5) ? (((uint32_t)(flo >> 60) | (fhi << 4)) & 0xfffu) : ((fhi >> (12 * g - 64)) & 0xfffu);
+                if ((uint32_t)g < fi) { off += fld & 15u; sat = sat || ((fld & 15u) == RH_FINE_SAT); }
+                if ((uint32_t)g == fi) mine = fld;
+            }
+            uint32_t sz = mine & 15u;
+            sat = sat || (sz == RH_FINE_SAT);
             uint32_t start = t[i].x + off;
-            if (sat) { // a group of 255 or more entries in front of / at the key: bounds by binary search
+            if (sat) { // a group of 15 or more entries in front of / at the key: bounds by binary search
                 const uint2 *__restrict__ E = a.ix.ent[LA0 + i];
-                const uint32_t end = reinterpret_cast<const uint2 *>(a.ix.bkt[LA0 + i])[prefix[i] + 1].x;
+                const uint32_t end = reinterpret_cast<const uint4 *>(a.ix.bkt[LA0 + i])[prefix[i] + 1].x;
                 uint32_t x = t[i].x, y = end;
                 while (x < y) { uint32_t mid = x + ((y - x) >> 1); if ((E[mid].x >> pbits) < fi) x = mid + 1; else y = mid; }
                 start = x; y = end;
                 while (x < y) { uint32_t mid = x + ((y - x) >> 1); if ((E[mid].x >> pbits) <= fi) x = mid + 1; else y = mid; }
                 sz = x - start;
             }
+            counted += sz;
+            if (sz == 1 && !sat) {
+                // a range of one entry: seed popcount filter (match.hpp:386) on the partner symbols the table
+                // knows; more than seedkmax known mismatches => the entry is never read (exact: the full
+                // count can only be larger)
+                const uint32_t x = (mine >> 4) ^ (rp[i] >> (pbits - dbits));
+                if (__popc(((x >> 1) | x) & 0x55u) > a.seedkmax) sz = 0;
+            }
             lo[i] = start; cum[i] = total; total += sz;
             s.cL++;
         }
     }
-    s.cC += total; s.cP += total;
+    s.cC += counted; s.cP += counted;
     // 2. enumerate, filter, queue, drain
     for (uint32_t kb = 0; kb < total && !(DEFER && s.p_n == PEND_OVF); kb += MQ) {
         const uint32_t kend = min(total, kb + (uint32_t)MQ);

@@ -299,7 +299,7 @@ extern "C" int real_hip_set_index_block(real_hip_ctx *ctx, uint64_t n, const voi
     ctx->have_index = false;
     ctx->n_entries = n;
     ctx->pb = rh_choose_prefix_bits(ctx, n);
-    ctx->fine = (ctx->prm.seedl - ctx->pb) <= 2 && ctx->prm.seedl >= ctx->pb && (ctx->prm.seedl - ctx->pb) >= 1;
+    ctx->fine = rh_is_fine(ctx->prm.seedl, ctx->pb);
     RhTimer tm(ctx, REAL_HIP_K_INDEX);
     int rc;
     if ((rc = rh_reserve(ctx, ctx->keys_a, (n ? n : 1) * sb))) return rc;
@@ -344,7 +344,7 @@ extern "C" int real_hip_index_download(real_hip_ctx *ctx, int list, uint32_t *en
     if (n && entries) RH_HIP(ctx, hipMemcpy(entries, ctx->ent[list].p, n * sizeof(uint2), hipMemcpyDeviceToHost));
     if (bucket) {
         const size_t nbk = ((size_t)1 << ctx->pb) + 1;
-        if (ctx->fine) RH_HIP(ctx, hipMemcpy2D(bucket, 4, ctx->bkt[list].p, 8, 4, nbk, hipMemcpyDeviceToHost)); // the .x of every uint2
+        if (ctx->fine) RH_HIP(ctx, hipMemcpy2D(bucket, 4, ctx->bkt[list].p, 16, 4, nbk, hipMemcpyDeviceToHost)); // the .x of every uint4
         else RH_HIP(ctx, hipMemcpy(bucket, ctx->bkt[list].p, nbk * 4, hipMemcpyDeviceToHost));
     }
     return REAL_HIP_OK;

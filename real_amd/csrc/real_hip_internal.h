@@ -33,15 +33,20 @@ struct DevText {
 // reference's equal range appear in the reference's order.
 struct DevIndex {
     const uint2    *ent[6];
-    const uint32_t *bkt[6]; // 2^pb + 1 bucket starts (u32), or in fine mode uint2 {start, key-group sizes}
+    const uint32_t *bkt[6]; // 2^pb + 1 bucket starts (u32), or in fine mode uint4 {start, 8 x {size:4, partner digest:8}}
     uint64_t n;
     uint32_t pb;     // prefix bits
     uint32_t pshift; // sig_bits - pb: prefix = sign >> pshift
     uint32_t fshift; // entry.x = [fbits of (sign >> fshift)] [pbits of the partner signature's top bits]
     uint32_t fbits;  // signature bits kept in the entry (all sig_bits - pb of them when that is <= 30)
     uint32_t pbits;  // partner-signature bits kept in the entry (even; 0 when the signature needs all 32)
-    uint32_t fine;   // 1: fbits <= 2 and the bucket table carries the sizes of the key groups of every bucket
+    uint32_t fine;   // 1: fbits <= 3 and the bucket table carries size + partner digest of the key groups of every bucket
 };
+
+// "fine" bucket tables: the prefix is all signature bits but one to three, so a bucket has at most eight key
+// groups (= signature values) and its 16-byte table entry describes each of them
+static inline bool rh_is_fine(uint32_t l, uint32_t pb) { return l >= pb && l - pb >= 1 && l - pb <= 3; }
+#define RH_FINE_SAT 15u /* group size field: 15 = "15 or more", bounds by binary search */
 
 // entry geometry shared by the index build and the matcher
 static inline void rh_index_geometry(uint32_t l, uint32_t pb, uint32_t *pshift, uint32_t *fshift, uint32_t *fbits, uint32_t *pbits)

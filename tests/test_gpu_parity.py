@@ -126,11 +126,12 @@ def test_match_all_golden_inputs(ora, path):
     (32, 100, 3, 1, 4),          # 16 buckets: every bucket is large -> in-bucket binary search path
     (64, 150, 5, 1, 12),         # signature wider than prefix+32: fingerprint + text confirmation path
     (16, 50, 4, 1, 0), (20, 255, 15, 1, 0), (4, 20, 2, 0, 0), (32, 32, 2, 1, 0),
-    # fine bucket tables (prefix = all signature bits but two / one): equal ranges straight from the table
-    (16, 50, 4, 1, 14), (16, 50, 4, 0, 14), (12, 40, 4, 1, 11), (8, 30, 3, 1, 6), (32, 100, 3, 1, 30),
+    # fine bucket tables (prefix = all signature bits but three / two / one): equal ranges straight from the table
+    (16, 50, 4, 1, 13), (16, 50, 4, 1, 14), (16, 50, 4, 0, 13), (12, 40, 4, 1, 11), (8, 30, 3, 1, 5), (8, 30, 3, 1, 6),
+    (32, 100, 3, 1, 29),
 ])
 def test_match_unique_random(ora, seedl, patl, k, scores, pb):
-    # (short seeds on a 3 kbp genome: equal ranges of hundreds of entries -> queue refills, 255-saturated groups)
+    # (short seeds on a 3 kbp genome: equal ranges of hundreds of entries -> queue refills, saturated groups)
     g = synth.random_genome(200_000 if seedl >= 16 else 3000, seed=100 + seedl + patl, n_frag=5, n_runs=20, repeats=30)
     b = synth.sample_reads(g, 4000 if seedl >= 16 else 300, patl, 0.02, seed=200 + patl, n_read_prob=0.0005)
     seedk = min(2, k)
@@ -154,7 +155,7 @@ def test_match_all_fine_tables(ora):
     ix = ora.Index(og, 16)
     p = ora.make_params(seedl=16, seedkmax=2, totalkmax=3, scores=1)
     ohits, ooff, octr = ora.match_all(og, ix, p, b.bases, b.qual, b.offsets)
-    m = AllMatcher(_opts(16, 2, 3, 1), prefix_bits=14)
+    m = AllMatcher(_opts(16, 2, 3, 1), prefix_bits=13)
     m.set_text_symbols(0, g.sym, g.frag_start)
     m.build_index_block()
     hits, hoff = m.match_all(b.bases, b.qual, b.offsets)
