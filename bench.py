@@ -290,12 +290,12 @@ def main():
                                                                                args.totalk, "on" if args.scores else "off", world),
                        "genome_bp": G, "reads_per_gpu_per_step": n, "read_len": args.patl, "seedl": args.seedl,
                        "seedkmax": 2, "totalkmax": args.totalk, "scores": bool(args.scores), "errprob": 0.02,
-                       "index_entries": n_entries, "prefix_bits": m.prefix_bits,
+                       "index_entries": n_entries, "prefix_bits": m.prefix_bits, "bucket_tables": ("starts", "digest", "fingerprint")[m.table_kind],
                        "parallelism": "reads sharded x%d, index replicated, one RCCL gather of records" % world,
                        "uniquely_aligned_frac_rank0": aligned / n, "index_build_s": t_index, "setup_s": t_setup},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "match_kernel<W=%d,scores=%d,unique,fine=%d>" % ((args.patl + 31) // 32, args.scores, int(args.seedl - m.prefix_bits <= 2)), "avg_launch_ms": avg_ms, "launches": match_n,
+                         "kernel": "match_kernel<W=%d,scores=%d,unique,tables=%s>" % ((args.patl + 31) // 32, args.scores, ("starts", "digest", "fingerprint")[m.table_kind]), "avg_launch_ms": avg_ms, "launches": match_n,
                          "algorithmic_bytes_per_read": a_total / max(ctr["reads"], 1),
                          "repeat_pass_avg_ms": rep_ms / max(rep_n, 1),
                          "work_per_read": {k: ctr[k] / max(ctr["reads"], 1) for k in ("lookups", "probes", "candidates", "seedpass", "hits", "verified")}},

@@ -84,30 +84,40 @@ int rh_count_wild(real_hip_ctx *ctx, uint64_t n)
 // ---------------------------------------------------------------------------
 // index layout from a sorted list
 // ---------------------------------------------------------------------------
-uint32_t rh_choose_prefix_bits(const real_hip_ctx *ctx, uint64_t n_entries)
+void rh_choose_tables(real_hip_ctx *ctx, uint64_t n_entries)
 {
-    uint32_t l = ctx->prm.seedl;
+    const uint32_t l = ctx->prm.seedl, want = ctx->prm.table_kind;
     uint32_t pb = ctx->prm.prefix_bits;
-    if (!pb) {
-        uint32_t lg = 0;
-        while ((1ull << (lg + 1)) <= (n_entries ? n_entries : 1)) lg++;
-        if (l <= 32 && lg >= 27) {
+    const bool auto_pb = (pb == 0);
+    uint32_t lg = 0;
+    while ((1ull << (lg + 1)) <= (n_entries ? n_entries : 1)) lg++;
+    const bool big = lg >= 27 && want != 1;
+    if (auto_pb) {
+        if (l <= 32 && big) {
             // large index, 32-bit signatures: prefix = all signature bits but three ("fine" tables: the bucket
             // table also holds size and partner digest of the (at most eight) key groups of a bucket, so a
             // lookup lands on the reference's equal range without scanning, and on nothing at all when the
             // range is one chance entry); 16 B x 2^(l-3) per list
             pb = l - 3;
+        } else if (l > 32 && big) {
+            // large index, 64-bit signatures: mean bucket of 4..8 entries, described by fingerprints
+            pb = lg - 2;
         } else {
             // mean bucket of 2..4 entries (the first two entries of every bucket are prefetched together)
             pb = lg > 1 ? lg - 1 : 1;
             if (pb < 8) pb = 8;
         }
-        if (pb > 30) pb = 30;
     }
     if (pb > l) pb = l; // a signature has seedl bits (two segments of seedl/4 bases)
     if (pb > 30) pb = 30;
     if (pb < 1) pb = 1;
-    return pb;
+    ctx->pb = pb;
+    uint32_t pshift, fshift, fbits, pbits;
+    rh_index_geometry(l, pb, &pshift, &fshift, &fbits, &pbits);
+    if (want == 1) ctx->fine = 0;
+    else if (rh_is_fine(l, pb)) ctx->fine = 1;
+    else if (pbits == 0 && (want == 2 || (auto_pb && big))) ctx->fine = 2;
+    else ctx->fine = 0;
 }
 
 __device__ __forceinline__ uint64_t dev_text_bits(const uint64_t *__restrict__ T, uint64_t i, unsigned nb)
@@ -192,6 +202,31 @@ __global__ void fine_table_kernel(const uint32_t *__restrict__ bkt, const uint2 
     out[p] = make_uint4(start, (uint32_t)lo, (uint32_t)(lo >> 32), hi);
 }
 
+// fingerprint bucket table (entries hold a 32-bit key, the signature is wider): uint4 {start, count:8 |
+// fingerprint:11 x 8}.  count saturates at 255; only the first RH_FP_SLOTS entries are described, a bucket
+// with more is searched by key.
+__global__ void fp_table_kernel(const uint32_t *__restrict__ bkt, const uint2 *__restrict__ ent, uint64_t nbuckets,
+                                uint4 *__restrict__ out)
+{
+    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > nbuckets) return;
+    const uint32_t start = bkt[p];
+    uint32_t cnt = 0;
+    uint64_t lo = 0, hi = 0; // 96-bit string: count in bits 0..7, fingerprint j in bits 8+11j ..
+    if (p < nbuckets) {
+        const uint32_t end = bkt[p + 1];
+        cnt = end - start;
+        for (uint32_t j = 0; j < cnt && j < RH_FP_SLOTS; ++j) {
+            const uint64_t f = rh_fp11(ent[start + j].x);
+            const uint32_t b = 8 + 11 * j;
+            if (b < 64) { lo |= f << b; if (b + 11 > 64) hi |= f >> (64 - b); }
+            else hi |= f << (b - 64);
+        }
+        lo |= cnt < 255 ? cnt : 255;
+    }
+    out[p] = make_uint4(start, (uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi);
+}
+
 int rh_index_from_sorted(real_hip_ctx *ctx, int list, const void *d_sign, const uint32_t *d_pos, uint64_t n,
                          unsigned sig_bytes)
 {
@@ -221,9 +256,13 @@ int rh_index_from_sorted(real_hip_ctx *ctx, int list, const void *d_sign, const 
     if (ctx->fine) {
         DevBuf fine_tab;
         if ((rc = rh_reserve(ctx, fine_tab, ((size_t)nb + 1) * sizeof(uint4)))) return rc;
-        hipLaunchKernelGGL(fine_table_kernel, dim3((unsigned)(((uint64_t)nb + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
-                           (const uint32_t *)ctx->bkt[list].p, (const uint2 *)ctx->ent[list].p, (uint64_t)nb, pbits, fbits,
-                           (uint4 *)fine_tab.p);
+        if (ctx->fine == 1)
+            hipLaunchKernelGGL(fine_table_kernel, dim3((unsigned)(((uint64_t)nb + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (const uint32_t *)ctx->bkt[list].p, (const uint2 *)ctx->ent[list].p, (uint64_t)nb, pbits, fbits,
+                               (uint4 *)fine_tab.p);
+        else
+            hipLaunchKernelGGL(fp_table_kernel, dim3((unsigned)(((uint64_t)nb + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (const uint32_t *)ctx->bkt[list].p, (const uint2 *)ctx->ent[list].p, (uint64_t)nb, (uint4 *)fine_tab.p);
         RH_HIP(ctx, hipGetLastError());
         RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
         rh_release(ctx->bkt[list]);
@@ -288,6 +327,7 @@ static int sort_list(real_hip_ctx *ctx, int list, const uint32_t *d_wpos, uint64
         RH_HIP(ctx, rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp, (K *)ctx->keys_a.p, (K *)ctx->keys_b.p, d_wpos,
                                               (uint32_t *)ctx->vals_b.p, (size_t)n, 0u, l, ctx->stream));
     }
+    rh_release(ctx->keys_a); // (hipFree waits for the sort) the unsorted keys are done with: room for this list's tables
     return rh_index_from_sorted(ctx, list, ctx->keys_b.p, (const uint32_t *)ctx->vals_b.p, n, sizeof(K));
 }
 
@@ -337,8 +377,7 @@ int rh_index_build_device(real_hip_ctx *ctx, uint64_t first_window, uint64_t max
         d_wpos = (const uint32_t *)ctx->vals_a.p + first_window;
     }
     ctx->n_entries = cnt;
-    ctx->pb = rh_choose_prefix_bits(ctx, cnt);
-    ctx->fine = rh_is_fine(l, ctx->pb);
+    rh_choose_tables(ctx, cnt);
     for (int k = 0; k < 6; ++k) {
         rc = (l <= 32) ? sort_list<uint32_t>(ctx, k, d_wpos, cnt) : sort_list<uint64_t>(ctx, k, d_wpos, cnt);
         if (rc) return rc;

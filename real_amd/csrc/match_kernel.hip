@@ -502,7 +502,8 @@ __device__ __forceinline__ void match_lists_fine(const MatchArgs &a, LaneState<W
     const uint64_t mb = (bb >= 64) ? ~0ull : ((1ull << bb) - 1);
     const uint64_t m[4] = {s.shi >> bb, s.shi & mb, s.slo >> bb, s.slo & mb};
     constexpr int NL = LA1 - LA0;
-    const uint32_t pbits = a.ix.pbits, pmask = (1u << pbits) - 1, G = 1u << a.ix.fbits;
+    const bool fpk = a.ix.fine == 2; // fingerprint tables: the entries hold a 32-bit key, membership is settled on the text
+    const uint32_t pbits = a.ix.pbits, pmask = (1u << pbits) - 1, G = fpk ? 1u : 1u << a.ix.fbits;
     uint32_t lo[NL], cum[NL], rp[NL], total = 0, counted = 0;
     const uint32_t dbits = pbits < 8 ? pbits : 8;
     {
@@ -518,14 +519,46 @@ __device__ __forceinline__ void match_lists_fine(const MatchArgs &a, LaneState<W
             f[i] = (uint32_t)sa & (G - 1);
             const int lb = 5 - la; // partner signature s_b = signature of list 5-la
             const int xb = (lb < 3) ? 0 : (lb < 5) ? 1 : 2, xd = (lb == 0) ? 1 : (lb == 1 || lb == 3) ? 2 : 3;
-            rp[i] = (uint32_t)(((m[xb] << bb) | m[xd]) >> (a.l - pbits));
+            rp[i] = fpk ? (uint32_t)(sa >> a.ix.fshift) : (uint32_t)(((m[xb] << bb) | m[xd]) >> ((a.l - pbits) & 63u));
             t[i] = reinterpret_cast<const uint4 *>(a.ix.bkt[la])[prefix[i]];
         }
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
-            // the entry's 96 bits = 8 fields {size:4, digest:8}, field g = key group g of the bucket
             const uint64_t flo = (uint64_t)t[i].y | ((uint64_t)t[i].z << 32);
-            const uint32_t fhi = t[i].w, fi = f[i];
+            const uint32_t fhi = t[i].w;
+            uint32_t start, sz;
+            if (fpk) {
+                // the entry's 96 bits = count:8, then the 11-bit fingerprints of the bucket's first eight keys
+                const uint32_t cnt = (uint32_t)flo & 255u, myfp = rh_fp11(rp[i]);
+                uint32_t first = RH_FP_SLOTS, last = 0;
+#pragma unroll
+                for (int j = 0; j < (int)RH_FP_SLOTS; ++j) {
+                    const int b = 8 + 11 * j;
+                    const uint32_t fld = (b + 11 <= 64) ? ((uint32_t)(flo >> b) & 0x7ffu)
+                                       : (b < 64) ? (((uint32_t)(flo >> b) | (fhi << (64 - b))) & 0x7ffu) : ((fhi >> (b - 64)) & 0x7ffu);
+                    if ((uint32_t)j < cnt && fld == myfp) { if (first == RH_FP_SLOTS) first = j; last = j; }
+                }
+                start = t[i].x + first;
+                sz = (first < RH_FP_SLOTS) ? last - first + 1 : 0u;
+                if (cnt > RH_FP_SLOTS && cnt < 255u) {
+                    // more than eight entries: everything from the first matching slot (or from the ninth entry) to
+                    // the end of the bucket is enumerated, the key comparison below sorts it out
+                    const uint32_t b0 = first; // RH_FP_SLOTS if none of the first eight matched
+                    start = t[i].x + b0;
+                    sz = cnt - b0;
+                } else if (cnt == 255u) { // a huge bucket: the equal range of the key by binary search
+                    const uint2 *__restrict__ E = a.ix.ent[LA0 + i];
+                    const uint32_t end = reinterpret_cast<const uint4 *>(a.ix.bkt[LA0 + i])[prefix[i] + 1].x;
+                    uint32_t x = t[i].x, y = end;
+                    while (x < y) { uint32_t mid = x + ((y - x) >> 1); if (E[mid].x < rp[i]) x = mid + 1; else y = mid; }
+                    start = x; y = end;
+                    while (x < y) { uint32_t mid = x + ((y - x) >> 1); if (E[mid].x <= rp[i]) x = mid + 1; else y = mid; }
+                    sz = x - start;
+                }
+                s.cP += sz;
+            } else {
+            // the entry's 96 bits = 8 fields {size:4, digest:8}, field g = key group g of the bucket
+            const uint32_t fi = f[i];
             uint32_t off = 0, mine = 0;
             bool sat = false;
 #pragma unroll
@@ -535,9 +568,9 @@ __device__ __forceinline__ void match_lists_fine(const MatchArgs &a, LaneState<W
                 if ((uint32_t)g < fi) { off += fld & 15u; sat = sat || ((fld & 15u) == RH_FINE_SAT); }
                 if ((uint32_t)g == fi) mine = fld;
             }
-            uint32_t sz = mine & 15u;
+            sz = mine & 15u;
             sat = sat || (sz == RH_FINE_SAT);
-            uint32_t start = t[i].x + off;
+            start = t[i].x + off;
             if (sat) { // a group of 15 or more entries in front of / at the key: bounds by binary search
                 const uint2 *__restrict__ E = a.ix.ent[LA0 + i];
                 const uint32_t end = reinterpret_cast<const uint4 *>(a.ix.bkt[LA0 + i])[prefix[i] + 1].x;
@@ -554,6 +587,7 @@ __device__ __forceinline__ void match_lists_fine(const MatchArgs &a, LaneState<W
                 // count can only be larger)
                 const uint32_t x = (mine >> 4) ^ (rp[i] >> (pbits - dbits));
                 if (__popc(((x >> 1) | x) & 0x55u) > a.seedkmax) sz = 0;
+            }
             }
             lo[i] = start; cum[i] = total; total += sz;
             s.cL++;
@@ -590,7 +624,7 @@ __device__ __forceinline__ void match_lists_fine(const MatchArgs &a, LaneState<W
                     // seedkmax known mismatches => rejected without touching the text (exact: the full count can
                     // only be larger)
                     const uint32_t x = (e[u].x & pmask) ^ r;
-                    if (__popc(((x >> 1) | x) & 0x55555555u) <= a.seedkmax) {
+                    if (fpk ? (e[u].x == r) : (__popc(((x >> 1) | x) & 0x55555555u) <= a.seedkmax)) {
                         q_pos[qn * 64] = e[u].y;
                         q_la[qn * 64] = (uint8_t)(LA0 + li[u]);
                         qn++;

@@ -298,8 +298,7 @@ extern "C" int real_hip_set_index_block(real_hip_ctx *ctx, uint64_t n, const voi
     const unsigned sb = ctx->prm.seedl <= 32 ? 4 : 8; // real.cpp:219-229
     ctx->have_index = false;
     ctx->n_entries = n;
-    ctx->pb = rh_choose_prefix_bits(ctx, n);
-    ctx->fine = rh_is_fine(ctx->prm.seedl, ctx->pb);
+    rh_choose_tables(ctx, n);
     RhTimer tm(ctx, REAL_HIP_K_INDEX);
     int rc;
     if ((rc = rh_reserve(ctx, ctx->keys_a, (n ? n : 1) * sb))) return rc;
@@ -332,6 +331,14 @@ extern "C" int real_hip_index_info(const real_hip_ctx *ctx, uint64_t *n_entries,
     if (!ctx || !ctx->have_index) return REAL_HIP_E_STATE;
     if (n_entries) *n_entries = ctx->n_entries;
     if (prefix_bits) *prefix_bits = ctx->pb;
+    return REAL_HIP_OK;
+}
+
+extern "C" int real_hip_index_table_kind(const real_hip_ctx *ctx, uint32_t *kind)
+{
+    if (!ctx || !kind) return REAL_HIP_E_INVALID;
+    if (!ctx->have_index) return REAL_HIP_E_STATE;
+    *kind = (uint32_t)ctx->fine;
     return REAL_HIP_OK;
 }
 
@@ -430,7 +437,7 @@ static void fill_args(real_hip_ctx *ctx, const Staged &s, uint64_t n, MatchArgs 
     for (int k = 0; k < 6; ++k) { a.ix.ent[k] = (const uint2 *)ctx->ent[k].p; a.ix.bkt[k] = (const uint32_t *)ctx->bkt[k].p; }
     a.ix.n = ctx->n_entries; a.ix.pb = pb;
     rh_index_geometry(l, pb, &a.ix.pshift, &a.ix.fshift, &a.ix.fbits, &a.ix.pbits);
-    a.ix.fine = ctx->fine ? 1u : 0u;
+    a.ix.fine = (uint32_t)ctx->fine;
     a.b.bases = s.bases; a.b.qual = ctx->prm.scores ? s.qual : nullptr; a.b.off = s.off;
     a.b.n_reads = n; a.b.upatl = s.upatl; a.b.W = s.W;
     a.LL = (const double *)ctx->LL.p;

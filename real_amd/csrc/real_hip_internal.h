@@ -40,13 +40,18 @@ struct DevIndex {
     uint32_t fshift; // entry.x = [fbits of (sign >> fshift)] [pbits of the partner signature's top bits]
     uint32_t fbits;  // signature bits kept in the entry (all sig_bits - pb of them when that is <= 30)
     uint32_t pbits;  // partner-signature bits kept in the entry (even; 0 when the signature needs all 32)
-    uint32_t fine;   // 1: fbits <= 3 and the bucket table carries size + partner digest of the key groups of every bucket
+    uint32_t fine;   // bucket table kind: 0 u32 starts; 1 "fine": size + partner digest of every key group of the bucket
+                     // (fbits <= 3); 2 fingerprints of the bucket's first entries (pbits == 0, wide signatures)
 };
 
 // "fine" bucket tables: the prefix is all signature bits but one to three, so a bucket has at most eight key
 // groups (= signature values) and its 16-byte table entry describes each of them
 static inline bool rh_is_fine(uint32_t l, uint32_t pb) { return l >= pb && l - pb >= 1 && l - pb <= 3; }
 #define RH_FINE_SAT 15u /* group size field: 15 = "15 or more", bounds by binary search */
+// fingerprint tables: uint4 {start, count:8 | 8 x fingerprint:11}: the first eight entries of the bucket by an
+// 11-bit hash of their 32-bit key; a lookup whose own fingerprint is not among them reads no entry at all
+#define RH_FP_SLOTS 8u
+static inline __host__ __device__ uint32_t rh_fp11(uint32_t key) { return (key * 0x9E3779B1u) >> 21; }
 
 // entry geometry shared by the index build and the matcher
 static inline void rh_index_geometry(uint32_t l, uint32_t pb, uint32_t *pshift, uint32_t *fshift, uint32_t *fbits, uint32_t *pbits)
@@ -116,7 +121,7 @@ struct real_hip_ctx {
     DevBuf ent[6], bkt[6];
     uint64_t n_entries = 0;
     uint32_t pb = 0;
-    bool fine = false; // bucket tables are uint2 {start, group sizes} (signature bits below the prefix <= 2)
+    int fine = 0;      // bucket table kind, see DevIndex::fine
     bool have_index = false;
 
     // tables / counters
@@ -172,4 +177,4 @@ int rh_index_from_sorted(real_hip_ctx *ctx, int list, const void *d_sign, const 
                          uint64_t n, unsigned sig_bytes);
 int rh_index_build_device(real_hip_ctx *ctx, uint64_t first_window, uint64_t max_entries,
                           uint64_t *n_entries, int *have_next);
-uint32_t rh_choose_prefix_bits(const real_hip_ctx *ctx, uint64_t n_entries);
+void rh_choose_tables(real_hip_ctx *ctx, uint64_t n_entries); // sets ctx->pb and ctx->fine

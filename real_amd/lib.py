@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "real_hip_scoring_table", "real_hip_create", "real_hip_destroy", "real_hip_strerror",
     "real_hip_last_error", "real_hip_abi_version", "real_hip_device_memory", "real_hip_set_text", "real_hip_set_text_symbols",
     "real_hip_set_index_block", "real_hip_build_index_block", "real_hip_index_info",
-    "real_hip_index_download", "real_hip_index_export", "real_hip_match_unique", "real_hip_match_all",
+    "real_hip_index_table_kind", "real_hip_index_download", "real_hip_index_export", "real_hip_match_unique", "real_hip_match_all",
     "real_hip_counters_get", "real_hip_kernel_time", "real_hip_timing_enable",
 ]
 
@@ -39,7 +39,7 @@ ABI_SYMBOLS = [
 class RealHipParams(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("seedl", C.c_uint32), ("seedkmax", C.c_uint32),
                 ("totalkmax", C.c_uint32), ("scores", C.c_uint32), ("prefix_bits", C.c_uint32),
-                ("device", C.c_int32), ("reserved", C.c_uint32), ("filter_mult", C.c_double),
+                ("device", C.c_int32), ("table_kind", C.c_uint32), ("filter_mult", C.c_double),
                 ("LL", C.c_double * 1024)]
 
 
@@ -97,6 +97,7 @@ def load():
     L.real_hip_set_index_block.argtypes = [vp, u64, C.POINTER(vp), C.POINTER(vp)]
     L.real_hip_build_index_block.argtypes = [vp, u64, u64, C.POINTER(u64), C.POINTER(C.c_int)]
     L.real_hip_index_info.argtypes = [vp, C.POINTER(u64), C.POINTER(u32)]
+    L.real_hip_index_table_kind.argtypes = [vp, C.POINTER(u32)]
     L.real_hip_index_download.argtypes = [vp, C.c_int, vp, vp]
     L.real_hip_index_export.argtypes = [vp, C.c_int, vp, vp]
     L.real_hip_match_unique.argtypes = [vp, C.POINTER(RealHipBatch), vp, vp]

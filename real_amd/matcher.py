@@ -120,7 +120,8 @@ def unpack_info(info: np.ndarray):
 class HipMatcher:
     """One context on one MI355X: resident text + index block + matching calls."""
 
-    def __init__(self, opts: RealOptions, device: int = 0, prefix_bits: int = 0, LL: Optional[np.ndarray] = None):
+    def __init__(self, opts: RealOptions, device: int = 0, prefix_bits: int = 0, LL: Optional[np.ndarray] = None,
+                 table_kind: int = 0):
         self.opts = opts
         self._L = _lib.load()
         p = RealHipParams()
@@ -128,6 +129,7 @@ class HipMatcher:
         p.seedl, p.seedkmax, p.totalkmax = opts.seedl, opts.seedkmax, opts.totalkmax
         p.scores = int(bool(opts.scores))
         p.prefix_bits = prefix_bits
+        p.table_kind = table_kind          # 0 auto, 1 bucket starts only, 2 directory entries (real_hip.h)
         p.device = device
         p.filter_mult = opts.filter_mult
         if LL is None:
@@ -197,6 +199,9 @@ class HipMatcher:
         pb = C.c_uint32(0)
         self._check(self._L.real_hip_index_info(self._h, C.byref(n), C.byref(pb)))
         self.n_entries, self.prefix_bits = int(n.value), int(pb.value)
+        tk = C.c_uint32(0)
+        self._check(self._L.real_hip_index_table_kind(self._h, C.byref(tk)))
+        self.table_kind = int(tk.value)
 
     def index_download(self, k: int, want_buckets: bool = True):
         """device layout of list k: entries (n x {fingerprint, pos}) and bucket starts."""

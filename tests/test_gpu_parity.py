@@ -129,6 +129,8 @@ def test_match_all_golden_inputs(ora, path):
     # fine bucket tables (prefix = all signature bits but three / two / one): equal ranges straight from the table
     (16, 50, 4, 1, 13), (16, 50, 4, 1, 14), (16, 50, 4, 0, 13), (12, 40, 4, 1, 11), (8, 30, 3, 1, 5), (8, 30, 3, 1, 6),
     (32, 100, 3, 1, 29),
+    # fingerprint bucket tables (64-bit signatures): mean bucket 6 (some overflow eight slots), 0.4 and 50 entries
+    (64, 150, 5, 1, -15), (64, 150, 5, 0, -19), (48, 100, 4, 1, -12), (36, 80, 3, 1, -4),
 ])
 def test_match_unique_random(ora, seedl, patl, k, scores, pb):
     # (short seeds on a 3 kbp genome: equal ranges of hundreds of entries -> queue refills, saturated groups)
@@ -137,7 +139,7 @@ def test_match_unique_random(ora, seedl, patl, k, scores, pb):
     seedk = min(2, k)
     p = ora.make_params(seedl=seedl, seedkmax=seedk, totalkmax=k, scores=scores)
     oinfo, oscore, octr = _oracle_unique(ora, None, g.sym, g.frag_start, seedl, 0, p, b.bases, b.qual, b.offsets)
-    m = UniqueMatcher(_opts(seedl, seedk, k, scores), prefix_bits=pb)
+    m = UniqueMatcher(_opts(seedl, seedk, k, scores), prefix_bits=abs(pb), table_kind=2 if pb < 0 else 0)   # pb < 0: directory tables forced
     m.set_text_symbols(0, g.sym, g.frag_start)
     m.build_index_block()
     info, score = m.match_unique(b.bases, b.qual, patl=patl)        # uniform-length batch form
