@@ -16,6 +16,8 @@
 
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 #include <rocprim/device/device_select.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
 
@@ -396,76 +398,120 @@ int rh_index_build_device(real_hip_ctx *ctx, uint64_t first_window, uint64_t max
 // matchAll post-pass: order the raw hit records per read as unifyMatches does
 // (operator<, matchAllImplementation.cpp:122-136: k, pos, file, frag, score, inverted;
 // file is constant inside a call and frag is a monotone function of pos).
+// The matcher appends hits in wave order and counts them per read; a read has a handful of
+// hits, so: offsets = exclusive scan of the counts, scatter every raw record into its read's
+// segment, rank the records of a segment against each other (one thread per read; one
+// workgroup per read with more than ALL_SMALL hits).  No global sort.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t float_order(uint32_t b) { return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+#define ALL_SMALL 32u
 
-__global__ void all_keys_lo_kernel(const uint4 *__restrict__ raw, uint64_t n, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+struct U32ToU64 {
+    __host__ __device__ uint64_t operator()(uint32_t v) const { return (uint64_t)v; }
+};
+
+__device__ __forceinline__ bool hit_less(const uint4 &x, const uint4 &y)
 {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint4 h = raw[i];
-    uint32_t inv = (h.w >> 8) & 1;
-    keys[i] = ((uint64_t)(h.y & 15) << 33) | ((uint64_t)float_order(h.z) << 1) | inv;
-    vals[i] = (uint32_t)i;
+    const uint32_t kx = x.w & 0xffu, ky = y.w & 0xffu;
+    if (kx != ky) return kx < ky;
+    if (x.y != y.y) return x.y < y.y;
+    const float sx = __uint_as_float(x.z), sy = __uint_as_float(y.z);
+    if (sx != sy) return sx < sy;
+    return ((x.w >> 8) & 1u) < ((y.w >> 8) & 1u);
 }
-__global__ void all_keys_hi_kernel(const uint4 *__restrict__ raw, const uint32_t *__restrict__ vals, uint64_t n,
-                                   uint64_t *__restrict__ keys)
+__device__ __forceinline__ real_hip_hit hit_record(const uint4 &h)
 {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint4 h = raw[vals[i]];
-    keys[i] = ((uint64_t)h.x << 32) | ((uint64_t)(h.w & 15) << 28) | (uint64_t)(h.y >> 4);
-}
-__global__ void all_gather_kernel(const uint4 *__restrict__ raw, const uint32_t *__restrict__ vals, uint64_t n,
-                                  real_hip_hit *__restrict__ out)
-{
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint4 h = raw[vals[i]];
     real_hip_hit o;
     o.read = h.x; o.pos = h.y; o.score = __uint_as_float(h.z);
     o.frag = (uint16_t)(h.w >> 16); o.k = (uint8_t)(h.w & 0xff); o.inverted = (uint8_t)((h.w >> 8) & 1);
-    out[i] = o;
+    return o;
 }
-// hit_offsets[r] = first sorted hit whose read >= r
-__global__ void all_offsets_kernel(const real_hip_hit *__restrict__ hits, uint64_t n_hits, uint64_t n_reads,
-                                   uint64_t *__restrict__ off)
+
+__global__ void all_scatter_kernel(const uint4 *__restrict__ raw, uint64_t n, const uint64_t *__restrict__ off,
+                                   uint32_t *__restrict__ cursor, uint4 *__restrict__ seg)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4 h = raw[i];
+    seg[off[h.x] + atomicAdd(&cursor[h.x], 1u)] = h;
+}
+
+__global__ void all_rank_kernel(const uint4 *__restrict__ seg, const uint64_t *__restrict__ off, uint64_t n_reads,
+                                real_hip_hit *__restrict__ out, uint32_t *__restrict__ big_list, unsigned long long *big_count)
 {
     uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r > n_reads) return;
-    uint64_t lo = 0, hi = n_hits;
-    while (lo < hi) {
-        uint64_t mid = lo + ((hi - lo) >> 1);
-        if ((uint64_t)hits[mid].read < r) lo = mid + 1; else hi = mid;
+    if (r >= n_reads) return;
+    const uint64_t o = off[r];
+    const uint32_t c = (uint32_t)(off[r + 1] - o);
+    if (c > ALL_SMALL) { big_list[atomicAdd(big_count, 1ull)] = (uint32_t)r; return; }
+    for (uint32_t i = 0; i < c; ++i) {
+        const uint4 h = seg[o + i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < c; ++j) {
+            const uint4 g = seg[o + j];
+            rank += (hit_less(g, h) || (j < i && !hit_less(h, g))) ? 1u : 0u;
+        }
+        out[o + rank] = hit_record(h);
     }
-    off[r] = lo;
+}
+
+// reads with many hits (repeats): one workgroup per read, same ranking
+__global__ void all_rank_big_kernel(const uint4 *__restrict__ seg, const uint64_t *__restrict__ off, const uint32_t *__restrict__ big_list,
+                                    const unsigned long long *__restrict__ big_count, real_hip_hit *__restrict__ out)
+{
+    const uint64_t nb = *big_count;
+    for (uint64_t b = blockIdx.x; b < nb; b += gridDim.x) {
+        const uint64_t r = big_list[b], o = off[r];
+        const uint32_t c = (uint32_t)(off[r + 1] - o);
+        for (uint32_t i = threadIdx.x; i < c; i += blockDim.x) {
+            const uint4 h = seg[o + i];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < c; ++j) {
+                const uint4 g = seg[o + j];
+                rank += (hit_less(g, h) || (j < i && !hit_less(h, g))) ? 1u : 0u;
+            }
+            out[o + rank] = hit_record(h);
+        }
+    }
 }
 
 int rh_all_finish(real_hip_ctx *ctx, uint64_t n_raw, uint64_t n_reads, real_hip_hit *d_out, uint64_t *d_hit_offsets)
 {
     RhTimer tm(ctx, REAL_HIP_K_ALL_SORT);
     int rc;
-    if (n_raw) {
-        if ((rc = rh_reserve(ctx, ctx->keys_a, n_raw * 8))) return rc;
-        if ((rc = rh_reserve(ctx, ctx->keys_b, n_raw * 8))) return rc;
-        if ((rc = rh_reserve(ctx, ctx->vals_a, n_raw * 4))) return rc;
-        if ((rc = rh_reserve(ctx, ctx->vals_b, n_raw * 4))) return rc;
-        dim3 grid((unsigned)((n_raw + 255) / 256)), block(256);
-        const uint4 *raw = (const uint4 *)ctx->raw.p;
-        uint64_t *ka = (uint64_t *)ctx->keys_a.p, *kb = (uint64_t *)ctx->keys_b.p;
-        uint32_t *va = (uint32_t *)ctx->vals_a.p, *vb = (uint32_t *)ctx->vals_b.p;
-        hipLaunchKernelGGL(all_keys_lo_kernel, grid, block, 0, ctx->stream, raw, n_raw, ka, va);
-        size_t tmp = 0;
-        RH_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp, ka, kb, va, vb, (size_t)n_raw, 0u, 64u, ctx->stream));
-        if ((rc = rh_reserve(ctx, ctx->sort_tmp, tmp ? tmp : 8))) return rc;
-        RH_HIP(ctx, rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp, ka, kb, va, vb, (size_t)n_raw, 0u, 37u, ctx->stream));
-        hipLaunchKernelGGL(all_keys_hi_kernel, grid, block, 0, ctx->stream, raw, vb, n_raw, ka);
-        RH_HIP(ctx, rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp, ka, kb, vb, va, (size_t)n_raw, 0u, 64u, ctx->stream));
-        hipLaunchKernelGGL(all_gather_kernel, grid, block, 0, ctx->stream, raw, va, n_raw, d_out);
+    if (!n_reads) {
+        if (d_hit_offsets) RH_HIP(ctx, hipMemsetAsync(d_hit_offsets, 0, 8, ctx->stream));
+        return REAL_HIP_OK;
     }
-    if (d_hit_offsets)
-        hipLaunchKernelGGL(all_offsets_kernel, dim3((unsigned)((n_reads + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
-                           (const real_hip_hit *)d_out, n_raw, n_reads, d_hit_offsets);
+    uint64_t *off = d_hit_offsets;
+    if (!off) {
+        if ((rc = rh_reserve(ctx, ctx->hit_off, (n_reads + 1) * 8))) return rc;
+        off = (uint64_t *)ctx->hit_off.p;
+    }
+    uint32_t *cnt = (uint32_t *)ctx->hit_cnt.p; // written by the matcher for every read of the batch
+    RH_HIP(ctx, hipMemsetAsync(cnt + n_reads, 0, 4, ctx->stream));
+    {
+        rocprim::transform_iterator<const uint32_t *, U32ToU64, uint64_t> in((const uint32_t *)cnt, U32ToU64());
+        size_t tmp = 0;
+        RH_HIP(ctx, rocprim::exclusive_scan(nullptr, tmp, in, off, (uint64_t)0, (size_t)(n_reads + 1), rocprim::plus<uint64_t>(), ctx->stream));
+        if ((rc = rh_reserve(ctx, ctx->sort_tmp, tmp ? tmp : 8))) return rc;
+        RH_HIP(ctx, rocprim::exclusive_scan(ctx->sort_tmp.p, tmp, in, off, (uint64_t)0, (size_t)(n_reads + 1), rocprim::plus<uint64_t>(), ctx->stream));
+    }
+    if (n_raw) {
+        if ((rc = rh_reserve(ctx, ctx->keys_a, n_raw * sizeof(uint4)))) return rc;       // the per-read segments
+        if ((rc = rh_reserve(ctx, ctx->vals_a, n_reads * 4))) return rc;                  // scatter cursors
+        if ((rc = rh_reserve(ctx, ctx->big_list, n_reads * 4 + 8))) return rc;
+        unsigned long long *big_count = (unsigned long long *)((uint8_t *)ctx->big_list.p + n_reads * 4);
+        RH_HIP(ctx, hipMemsetAsync(ctx->vals_a.p, 0, n_reads * 4, ctx->stream));
+        RH_HIP(ctx, hipMemsetAsync(big_count, 0, 8, ctx->stream));
+        const uint4 *raw = (const uint4 *)ctx->raw.p;
+        uint4 *seg = (uint4 *)ctx->keys_a.p;
+        hipLaunchKernelGGL(all_scatter_kernel, dim3((unsigned)((n_raw + 255) / 256)), dim3(256), 0, ctx->stream, raw, n_raw,
+                           (const uint64_t *)off, (uint32_t *)ctx->vals_a.p, seg);
+        hipLaunchKernelGGL(all_rank_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, ctx->stream, (const uint4 *)seg,
+                           (const uint64_t *)off, n_reads, d_out, (uint32_t *)ctx->big_list.p, big_count);
+        hipLaunchKernelGGL(all_rank_big_kernel, dim3(1024), dim3(256), 0, ctx->stream, (const uint4 *)seg, (const uint64_t *)off,
+                           (const uint32_t *)ctx->big_list.p, (const unsigned long long *)big_count, d_out);
+    }
     RH_HIP(ctx, hipGetLastError());
     return REAL_HIP_OK;
 }

@@ -60,6 +60,7 @@ struct LaneState {
     uint32_t p_pos[NPEND], p_meta[NPEND]; // text position; k | strand << 8 | fragment << 16
     uint64_t p_tw[W];                     // aligned text words of pending location 0
     uint32_t p_n, p_nev, p_ev, cslot;     // locations, events, 1 bit per event (= location), slot of the memo
+    uint32_t nhit; // matchAll: hits appended for this read
     // work counters
     unsigned cL, cP, cC, cS, cH, cV;
 };
@@ -211,6 +212,7 @@ __device__ __forceinline__ void deliver(const MatchArgs &a, LaneState<W, SCORES,
     if (ALL) {
         unsigned long long slot = wave_append_slot(a.raw_count);
         if (slot < a.raw_cap) a.raw[slot] = make_uint4((uint32_t)s.r, pos, __float_as_uint(score), meta);
+        s.nhit++;
     } else {
         fold_update<SCORES>((meta >> 8) & 1, a.t.fileid, pos, meta & 0xff, score, s.eps, meta >> 16, s.info, s.iscore);
     }
@@ -766,7 +768,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
         }
         wave_lds_sync();
         // ---- match
-        s.r = r; s.patl = patl; s.p_n = 0;
+        s.r = r; s.patl = patl; s.p_n = 0; s.nhit = 0;
         if (elig) {
             if (!ALL) {
                 s.info = a.info[r];
@@ -801,13 +803,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
                 if (SCORES) a.score[r] = s.iscore;
             }
         }
+        if (ALL && r < n) a.hit_cnt[r] = (elig && !ovf) ? s.nhit : 0u; // (a handed-over read: the repeat kernel writes it)
     } else {
         const uint64_t n_items = (uint64_t)*a.ovf_count;
         for (uint64_t it = (uint64_t)blockIdx.x * 256 + threadIdx.x; it < n_items; it += (uint64_t)gridDim.x * 256) {
             const uint64_t r = a.ovf_list[it];
             const uint64_t o0 = a.b.off ? a.b.off[r] : r * (uint64_t)a.b.upatl;
             const uint32_t patl = a.b.off ? (uint32_t)(a.b.off[r + 1] - o0) : a.b.upatl;
-            s.r = r; s.o0 = o0; s.patl = patl;
+            s.r = r; s.o0 = o0; s.patl = patl; s.nhit = 0;
             pack_read<W>(GlobalRow{a.b.bases + o0}, patl, s.O); // (eligible: the matcher handed it over)
             if (!ALL) {
                 s.info = a.info[r];
@@ -818,6 +821,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
             if (!ALL) {
                 a.info[r] = s.info;
                 if (SCORES) a.score[r] = s.iscore;
+            } else {
+                a.hit_cnt[r] = s.nhit;
             }
         }
     }

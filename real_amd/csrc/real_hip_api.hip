@@ -189,7 +189,7 @@ extern "C" void real_hip_destroy(real_hip_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->text, &c->wild, &c->frag, &c->LL, &c->counters, &c->s_bases, &c->s_qual, &c->s_off, &c->s_info,
-                     &c->s_score, &c->maxpatl, &c->ovf_list, &c->ovf_count, &c->raw, &c->raw_count, &c->keys_a,
+                     &c->s_score, &c->maxpatl, &c->ovf_list, &c->ovf_count, &c->raw, &c->raw_count, &c->hit_cnt, &c->big_list, &c->keys_a,
                      &c->keys_b, &c->vals_a, &c->vals_b, &c->sort_tmp, &c->hit_off, &c->s_hits};
     for (DevBuf *b : all) rh_release(*b);
     for (int k = 0; k < 6; ++k) { rh_release(c->ent[k]); rh_release(c->bkt[k]); }
@@ -498,7 +498,9 @@ extern "C" int real_hip_match_all(real_hip_ctx *ctx, const real_hip_batch *b, re
     if (n) {
         MatchArgs a;
         fill_args(ctx, s, n, a);
+        if ((rc = rh_reserve(ctx, ctx->hit_cnt, (n + 1) * 4))) return rc;
         a.raw = (uint4 *)ctx->raw.p; a.raw_count = (unsigned long long *)ctx->raw_count.p; a.raw_cap = cap;
+        a.hit_cnt = (uint32_t *)ctx->hit_cnt.p;
         if ((rc = rh_launch_match(ctx, a, true))) return rc;
         RH_HIP(ctx, hipMemcpyAsync(&n_raw, ctx->raw_count.p, 8, hipMemcpyDeviceToHost, ctx->stream));
         RH_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -91,6 +91,7 @@ struct MatchArgs {
     uint4 *raw;            // raw hit records
     unsigned long long *raw_count;
     uint64_t raw_cap;
+    uint32_t *hit_cnt;     // [n_reads] hits appended per read (every read of the batch is written)
     // reads handed from the matcher to the repeat kernel (scores on)
     uint32_t *ovf_list;
     unsigned long long *ovf_count;
@@ -131,7 +132,7 @@ struct real_hip_ctx {
     DevBuf s_bases, s_qual, s_off, s_info, s_score;
     DevBuf maxpatl, ovf_list, ovf_count;
     // matchAll workspace
-    DevBuf raw, raw_count, keys_a, keys_b, vals_a, vals_b, sort_tmp, hit_off, s_hits;
+    DevBuf raw, raw_count, hit_cnt, big_list, keys_a, keys_b, vals_a, vals_b, sort_tmp, hit_off, s_hits;
 
     // timing
     bool timing = true;

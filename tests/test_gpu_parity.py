@@ -170,6 +170,33 @@ def test_match_all_fine_tables(ora):
     m.close()
 
 
+@pytest.mark.parametrize("scores", [1, 0])
+def test_match_all_many_hits_per_read(ora, scores):
+    # 8-base seeds on a 3 kbp tandem repeat (period 40, 2 % diverged copies): tens of hits per read -- the per-read
+    # ordering pass takes its workgroup-per-read path (> 32 hits), the matcher its repeat pass (scores on)
+    g = synth.random_genome(3000, seed=31, n_frag=2)
+    rng = np.random.default_rng(33)
+    unit = rng.integers(0, 4, size=40, dtype=np.uint8)
+    g.sym[:] = np.where(rng.random(3000) < 0.02, rng.integers(0, 4, size=3000, dtype=np.uint8), np.tile(unit, 75))
+    b = synth.sample_reads(g, 400, 30, 0.03, seed=32)
+    og = ora.Genome(g.sym, g.frag_start)
+    ix = ora.Index(og, 8)
+    p = ora.make_params(seedl=8, seedkmax=2, totalkmax=4, scores=scores)
+    ohits, ooff, octr = ora.match_all(og, ix, p, b.bases, b.qual, b.offsets)
+    assert int(np.diff(ooff).max()) > 32, "test data must hold a read with more than 32 hits"
+    m = AllMatcher(_opts(8, 2, 4, scores))
+    m.set_text_symbols(0, g.sym, g.frag_start)
+    m.build_index_block()
+    hits, hoff = m.match_all(b.bases, b.qual, b.offsets, cap=len(ohits) + 8)   # (no overflow retry: work counted once)
+    assert np.array_equal(hoff, ooff)
+    for x, y in zip(_hits_tuple(hits), _hits_tuple(ohits)):
+        assert np.array_equal(x, y)
+    c = m.counters()
+    for k in ("reads", "lookups", "candidates", "seedpass", "hits"):
+        assert c[k] == octr[k]
+    m.close()
+
+
 def test_index_layout_device_equals_host(ora):
     g = synth.random_genome(50_000, seed=77, n_frag=3, n_runs=10, repeats=10)
     for seedl in (32, 64, 12):
