@@ -27,9 +27,13 @@
 
 #define EB 8  // index entries a lane requests per round trip while enumerating equal ranges
 #define MQ 16 // candidate queue slots per lane (LDS); a full queue is drained and refilled
-// LDS bytes of one wave: its candidate queue (MQ x 64 positions + lists, 6 x 64 cursors) while it matches; before
-// and after, the staging area through which it reads the bases / qualities of its reads from the batch
-#define STG_BYTES (MQ * 64u * 5u + 6u * 64u * 4u)
+// LDS bytes of one wave: its candidate queue (MQ x 64 positions + lists, 6 x 64 cursors; the first 6.5 KiB) while
+// it matches; before and after, the staging area through which it reads the bases / qualities of its reads from
+// the batch.  9.5 KiB hold the 64 reads of a wave up to 151 bases each in one go; with the 8 KiB score table that
+// is 46 KiB per workgroup = three workgroups per CU, which is what the registers allow anyway.
+#define QUEUE_BYTES (MQ * 64u * 5u + 6u * 64u * 4u)
+__host__ __device__ constexpr uint32_t stg_bytes(int W) { return W <= 4 ? QUEUE_BYTES : 9728u; } // (reads up to 128 bases: as before)
+static_assert(stg_bytes(5) >= QUEUE_BYTES && stg_bytes(5) % 16 == 0 && QUEUE_BYTES % 16 == 0, "wave LDS region");
 #define STG_PAD 16u
 #define NPEND 2      // verified locations a lane parks until their scores are computed (flush_pending)
 #define PEND_EV 32   // update() events parked with them
@@ -733,13 +737,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
 {
     constexpr bool DEFER = SCORES && !REPEAT;
     __shared__ double sLL[SCORES ? 1024 : 1];
-    __shared__ __attribute__((aligned(16))) uint8_t smem[4 * STG_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t smem[4 * stg_bytes(W)];
     if (SCORES) {
         for (int i = threadIdx.x; i < 1024; i += 256) sLL[i] = a.LL[i];
         __syncthreads();
     }
     const uint32_t lane = threadIdx.x & 63;
-    uint8_t *stg = smem + (threadIdx.x >> 6) * STG_BYTES;
+    uint8_t *stg = smem + (threadIdx.x >> 6) * stg_bytes(W);
     uint32_t *q_pos = reinterpret_cast<uint32_t *>(stg) + lane;
     uint8_t *q_la = stg + MQ * 64 * 4 + lane;
     uint32_t *q_cur = reinterpret_cast<uint32_t *>(stg + MQ * 64 * 5) + lane;
@@ -900,7 +904,7 @@ int rh_launch_match(real_hip_ctx *ctx, const MatchArgs &args, bool all)
     { // reads a wave stages at a time: their bytes (+ alignment skew, pad, one dword of over-read) fit its LDS region
         const uint32_t maxlen = a.b.off ? 32u * a.b.W : a.b.upatl;
         uint32_t gl = 64;
-        while (gl > 1 && (uint64_t)gl * maxlen + STG_PAD + 16 + 16 > STG_BYTES) gl >>= 1;
+        while (gl > 1 && (uint64_t)gl * maxlen + STG_PAD + 16 + 16 > stg_bytes((int)a.b.W)) gl >>= 1;
         a.b.gl = gl;
     }
     if (sc) { // hand-over list of the reads the matcher leaves to the repeat kernel
