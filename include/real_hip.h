@@ -129,7 +129,9 @@ typedef struct real_hip_batch {
     uint32_t        struct_size;
     uint32_t        on_device;  /* 0: all pointers of the call are host memory (copied);
                                    1: all are device pointers (bases, qual, offsets and the
-                                      info / score / hit outputs)                         */
+                                      info / score / hit outputs);
+                                   2: bases, qual, offsets are device pointers (e.g. the arrays
+                                      real_hip_parse_reads returned), the outputs host memory   */
     uint64_t        n_reads;
     const uint8_t  *bases;      /* concatenated mapped symbols                          */
     const uint8_t  *qual;       /* concatenated qualities; NULL => 30 (Pattern.hpp:42-45) */
@@ -168,6 +170,30 @@ typedef struct real_hip_hit {       /* MatchPosAndError, matchAllImplementation.
 int real_hip_match_all(real_hip_ctx *ctx, const real_hip_batch *b,
                        real_hip_hit *out, uint64_t cap, uint64_t *n_out, uint64_t *hit_offsets);
 
+/* ---- read ingestion on the device: FASTA / FASTQ text -> the arrays of a batch.
+ * Replaces FastQReader / FastAReader::getNextPatternUnlocked (FastQReader.hpp:130-180,
+ * FastAReader.hpp:107-138), Pattern::computeMapped (Pattern.hpp:105-128, acgtnMap.hpp:39-50) and the
+ * quality offset subtraction (FastQReader.hpp:165-173) for text in canonical form: whole records, every
+ * field (id, sequence, '+', quality) on one line; "\r\n" accepted.  Anything else -- wrapped sequences,
+ * white space inside a field, a chunk that ends inside a record -- is refused with
+ * REAL_HIP_E_UNSUPPORTED and left to the caller's reader.  text: n_bytes < 4 GiB, host memory
+ * (copied) or device memory (text_on_device).  The returned arrays are device memory owned by ctx,
+ * valid until the next real_hip_parse_reads on it; id_start/id_len locate each record's id inside
+ * the text (behind its '@' / '>').                                                            */
+typedef struct real_hip_parsed {
+    uint32_t        struct_size;
+    uint32_t        max_patl;    /* longest read of the chunk                              */
+    uint64_t        n_reads;
+    uint64_t        n_symbols;   /* = offsets[n_reads]                                     */
+    const uint8_t  *bases;       /* mapped symbols 0..4, concatenated                      */
+    const uint8_t  *qual;        /* quality character - offset; NULL for FASTA             */
+    const uint64_t *offsets;     /* n_reads + 1                                            */
+    const uint32_t *id_start;    /* n_reads                                                */
+    const uint32_t *id_len;      /* n_reads                                                */
+} real_hip_parsed;
+int real_hip_parse_reads(real_hip_ctx *ctx, const char *text, uint64_t n_bytes, int text_on_device,
+                         int fastq, int quality_offset, real_hip_parsed *out);
+
 /* ---- work counters: accumulated since the last reset ---------- */
 typedef struct real_hip_counters {
     uint64_t reads;       /* R  reads matched (not skipped)                           */
@@ -185,7 +211,8 @@ int real_hip_counters_get(real_hip_ctx *ctx, real_hip_counters *out, int reset);
  * of the path; times are accumulated per kernel since the last reset.         */
 enum { REAL_HIP_K_MATCH_UNIQUE = 0, REAL_HIP_K_MATCH_ALL = 1, REAL_HIP_K_ALL_SORT = 2, REAL_HIP_K_INDEX = 3,
        REAL_HIP_K_MATCH_REPEAT = 4, /* second pass over the repeat-rich reads the matcher hands over (scores on) */
-       REAL_HIP_K_COUNT = 5 };
+       REAL_HIP_K_PARSE = 5,        /* real_hip_parse_reads                                                      */
+       REAL_HIP_K_COUNT = 6 };
 int real_hip_kernel_time(real_hip_ctx *ctx, int which, double *total_ms, uint64_t *launches, int reset);
 int real_hip_timing_enable(real_hip_ctx *ctx, int on);
 

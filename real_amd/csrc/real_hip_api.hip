@@ -189,7 +189,8 @@ extern "C" void real_hip_destroy(real_hip_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->text, &c->wild, &c->frag, &c->LL, &c->counters, &c->s_bases, &c->s_qual, &c->s_off, &c->s_info,
-                     &c->s_score, &c->maxpatl, &c->ovf_list, &c->ovf_count, &c->raw, &c->raw_count, &c->hit_cnt, &c->big_list, &c->keys_a,
+                     &c->s_score, &c->maxpatl, &c->ovf_list, &c->ovf_count, &c->raw, &c->raw_count, &c->hit_cnt, &c->big_list, &c->p_text, &c->p_nl, &c->p_scal, &c->p_spans, &c->p_off,
+                     &c->p_len1, &c->p_bases, &c->p_qual, &c->keys_a,
                      &c->keys_b, &c->vals_a, &c->vals_b, &c->sort_tmp, &c->hit_off, &c->s_hits};
     for (DevBuf *b : all) rh_release(*b);
     for (int k = 0; k < 6; ++k) { rh_release(c->ent[k]); rh_release(c->bkt[k]); }
@@ -458,7 +459,7 @@ extern "C" int real_hip_match_unique(real_hip_ctx *ctx, const real_hip_batch *b,
     if (!info || (sc && !score)) return rh_fail(ctx, REAL_HIP_E_INVALID, "null info/score", hipSuccess);
     uint64_t *d_info = info;
     float *d_score = score;
-    if (!b->on_device) {
+    if (b->on_device != 1) { // outputs in host memory
         if ((rc = rh_reserve(ctx, ctx->s_info, n * 8))) return rc;
         RH_HIP(ctx, hipMemcpyAsync(ctx->s_info.p, info, n * 8, hipMemcpyHostToDevice, ctx->stream));
         d_info = (uint64_t *)ctx->s_info.p;
@@ -472,7 +473,7 @@ extern "C" int real_hip_match_unique(real_hip_ctx *ctx, const real_hip_batch *b,
     fill_args(ctx, s, n, a);
     a.info = d_info; a.score = d_score;
     if ((rc = rh_launch_match(ctx, a, false))) return rc;
-    if (!b->on_device) {
+    if (b->on_device != 1) { // outputs in host memory
         RH_HIP(ctx, hipMemcpyAsync(info, d_info, n * 8, hipMemcpyDeviceToHost, ctx->stream));
         if (sc) RH_HIP(ctx, hipMemcpyAsync(score, d_score, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     }
@@ -509,7 +510,7 @@ extern "C" int real_hip_match_all(real_hip_ctx *ctx, const real_hip_batch *b, re
     if (n_raw > cap) return rh_fail(ctx, REAL_HIP_E_OVERFLOW, "hit buffer too small", hipSuccess);
     real_hip_hit *d_out = out;
     uint64_t *d_off = hit_offsets;
-    if (!b->on_device) {
+    if (b->on_device != 1) { // outputs in host memory
         if ((rc = rh_reserve(ctx, ctx->s_hits, (n_raw ? n_raw : 1) * sizeof(real_hip_hit)))) return rc;
         d_out = (real_hip_hit *)ctx->s_hits.p;
         if (hit_offsets) {
@@ -519,13 +520,32 @@ extern "C" int real_hip_match_all(real_hip_ctx *ctx, const real_hip_batch *b, re
     }
     if ((n_raw && !out) ) return rh_fail(ctx, REAL_HIP_E_INVALID, "null hit buffer", hipSuccess);
     if ((rc = rh_all_finish(ctx, n_raw, n, d_out, d_off))) return rc;
-    if (!b->on_device) {
+    if (b->on_device != 1) { // outputs in host memory
         if (n_raw) RH_HIP(ctx, hipMemcpyAsync(out, d_out, n_raw * sizeof(real_hip_hit), hipMemcpyDeviceToHost, ctx->stream));
         if (hit_offsets) RH_HIP(ctx, hipMemcpyAsync(hit_offsets, d_off, (n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
     }
     RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     rh_time_resolve(ctx);
     return REAL_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// read ingestion
+// ---------------------------------------------------------------------------
+extern "C" int real_hip_parse_reads(real_hip_ctx *ctx, const char *text, uint64_t n_bytes, int text_on_device, int fastq,
+                                    int quality_offset, real_hip_parsed *out)
+{
+    RH_ENTER(ctx);
+    if (!out || (n_bytes && !text)) return rh_fail(ctx, REAL_HIP_E_INVALID, "null text / out", hipSuccess);
+    const char *d_text = text;
+    if (!text_on_device && n_bytes) {
+        int rc = rh_reserve(ctx, ctx->p_text, n_bytes);
+        if (rc) return rc;
+        RH_HIP(ctx, hipMemcpyAsync(ctx->p_text.p, text, n_bytes, hipMemcpyHostToDevice, ctx->stream));
+        d_text = (const char *)ctx->p_text.p;
+    }
+    RhTimer tm(ctx, REAL_HIP_K_PARSE);
+    return rh_parse_reads(ctx, d_text, n_bytes, fastq, quality_offset, out);
 }
 
 // ---------------------------------------------------------------------------

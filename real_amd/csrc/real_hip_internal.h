@@ -131,6 +131,8 @@ struct real_hip_ctx {
     // batch staging (host batches), hand-over list of the repeat kernel
     DevBuf s_bases, s_qual, s_off, s_info, s_score;
     DevBuf maxpatl, ovf_list, ovf_count;
+    // read ingestion (read_parse.hip)
+    DevBuf p_text, p_nl, p_scal, p_spans, p_off, p_len1, p_bases, p_qual;
     // matchAll workspace
     DevBuf raw, raw_count, hit_cnt, big_list, keys_a, keys_b, vals_a, vals_b, sort_tmp, hit_off, s_hits;
 
@@ -169,6 +171,7 @@ void rh_time_begin(real_hip_ctx *ctx, hipStream_t st, int which);
 void rh_time_end(real_hip_ctx *ctx, hipStream_t st);
 void rh_time_resolve(real_hip_ctx *ctx); // call after the streams were synchronised
 int rh_max_patl(real_hip_ctx *ctx, const uint64_t *d_off, uint64_t n_reads, uint32_t *out);
+int rh_parse_reads(real_hip_ctx *ctx, const char *d_text, uint64_t n_bytes, int fastq, int qoff, real_hip_parsed *out);
 int rh_all_finish(real_hip_ctx *ctx, uint64_t n_raw, uint64_t n_reads, real_hip_hit *d_out,
                   uint64_t *d_hit_offsets);
 

@@ -24,7 +24,7 @@ REAL_HIP_E_STATE = -5
 REAL_HIP_E_UNSUPPORTED = -6
 REAL_HIP_MAX_PATL = 256
 
-K_MATCH_UNIQUE, K_MATCH_ALL, K_ALL_SORT, K_INDEX, K_MATCH_REPEAT = range(5)
+K_MATCH_UNIQUE, K_MATCH_ALL, K_ALL_SORT, K_INDEX, K_MATCH_REPEAT, K_PARSE = range(6)
 
 # every symbol include/real_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "real_hip_last_error", "real_hip_abi_version", "real_hip_device_memory", "real_hip_set_text", "real_hip_set_text_symbols",
     "real_hip_set_index_block", "real_hip_build_index_block", "real_hip_index_info",
     "real_hip_index_table_kind", "real_hip_index_download", "real_hip_index_export", "real_hip_match_unique", "real_hip_match_all",
-    "real_hip_counters_get", "real_hip_kernel_time", "real_hip_timing_enable",
+    "real_hip_parse_reads", "real_hip_counters_get", "real_hip_kernel_time", "real_hip_timing_enable",
 ]
 
 
@@ -47,6 +47,12 @@ class RealHipBatch(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("on_device", C.c_uint32), ("n_reads", C.c_uint64),
                 ("bases", C.c_void_p), ("qual", C.c_void_p), ("offsets", C.c_void_p),
                 ("patl", C.c_uint32), ("max_patl", C.c_uint32)]
+
+
+class RealHipParsed(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("max_patl", C.c_uint32), ("n_reads", C.c_uint64), ("n_symbols", C.c_uint64),
+                ("bases", C.c_void_p), ("qual", C.c_void_p), ("offsets", C.c_void_p),
+                ("id_start", C.c_void_p), ("id_len", C.c_void_p)]
 
 
 class RealHipCounters(C.Structure):
@@ -98,6 +104,7 @@ def load():
     L.real_hip_build_index_block.argtypes = [vp, u64, u64, C.POINTER(u64), C.POINTER(C.c_int)]
     L.real_hip_index_info.argtypes = [vp, C.POINTER(u64), C.POINTER(u32)]
     L.real_hip_index_table_kind.argtypes = [vp, C.POINTER(u32)]
+    L.real_hip_parse_reads.argtypes = [vp, vp, u64, C.c_int, C.c_int, C.c_int, C.POINTER(RealHipParsed)]
     L.real_hip_index_download.argtypes = [vp, C.c_int, vp, vp]
     L.real_hip_index_export.argtypes = [vp, C.c_int, vp, vp]
     L.real_hip_match_unique.argtypes = [vp, C.POINTER(RealHipBatch), vp, vp]

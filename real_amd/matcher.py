@@ -143,6 +143,7 @@ class HipMatcher:
             raise RealHipError(rc, self._L.real_hip_strerror(rc).decode() +
                                " (real_hip_create: is an MI355X visible? there is no CPU fallback)")
         self._h = h
+        self.device = device
         self.n_entries = 0
         self.prefix_bits = 0
 
@@ -265,6 +266,43 @@ class HipMatcher:
                 continue
             self._check(rc)
             return out[:int(nout.value)], hoff
+
+    # -- read ingestion on the device --
+    def parse_reads(self, text, fastq: bool, quality_offset: int = 33):
+        """FASTA / FASTQ text (bytes, numpy uint8 or a device torch tensor) -> RealHipParsed: device arrays owned by the
+        context, valid until the next parse.  Raises RealHipError(E_UNSUPPORTED) for text that is not in
+        one-line-per-field form (FastQReader.hpp:130-180 accepts more; the host reader handles that)."""
+        on_dev = bool(getattr(text, "is_cuda", False))
+        if not on_dev and not isinstance(text, np.ndarray):
+            text = np.frombuffer(text, dtype=np.uint8)
+        n = int(text.numel()) if on_dev else int(text.shape[0])
+        out = _lib.RealHipParsed()
+        self._check(self._L.real_hip_parse_reads(self._h, _ptr(text), n, int(on_dev), int(bool(fastq)), int(quality_offset), C.byref(out)))
+        return out
+
+    def match_unique_parsed(self, parsed, info=None, score=None):
+        """UniqueMatcher::match over the reads of a parse_reads() result (read arrays on the device, records on the host)."""
+        b = RealHipBatch()
+        b.struct_size = C.sizeof(RealHipBatch)
+        b.on_device = 2
+        b.n_reads = parsed.n_reads
+        b.bases, b.qual, b.offsets = parsed.bases, parsed.qual, parsed.offsets
+        b.patl, b.max_patl = 0, parsed.max_patl
+        if info is None:
+            info, score = new_unique_info(int(b.n_reads), self.opts.scores)
+        self._check(self._L.real_hip_match_unique(self._h, C.byref(b), _ptr(info), _ptr(score)))
+        return info, score
+
+    def download(self, dev_ptr, count: int, dtype):
+        """copy `count` items of a device array the library returned to the host (tests, id strings)"""
+        out = np.zeros(count, dtype=dtype)
+        if count:
+            hip = C.CDLL("libamdhip64.so")
+            hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+            rc = hip.hipMemcpy(out.ctypes.data, C.c_void_p(int(dev_ptr)), out.nbytes, 2)    # hipMemcpyDeviceToHost
+            if rc != 0:
+                raise RuntimeError("hipMemcpy device->host failed: %d" % rc)
+        return out
 
     # -- instrumentation --
     def counters(self, reset: bool = False) -> dict:
