@@ -129,7 +129,7 @@ def main():
     ap.add_argument("--prefix-bits", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
-    ap.add_argument("--mode", choices=["unique", "all"], default="unique",
+    ap.add_argument("--mode", choices=["unique", "all", "ingest"], default="unique",
                     help="unique = BASELINE configs[1] (default, what the driver runs); all = configs[2] (matchAll, manual runs)")
     ap.add_argument("--host-buffers", action="store_true",
                     help="hand the batch over as host buffers (PCIe-inclusive rate for DESIGN.md; never the headline value)")
@@ -181,6 +181,45 @@ def main():
     info = torch.zeros(n, dtype=torch.int64, device=dev)
     score = torch.empty(n, dtype=torch.float32, device=dev)
     t_setup = time.time() - t_setup
+
+    if args.mode == "ingest":
+        # side measurement of read ingestion on the device: FASTQ text of the step's reads, resident
+        # in HBM, parsed by real_hip_parse_reads into batch arrays; then matched from those arrays
+        nn = min(n, (4 * 2**30 - 2**20) // (2 * args.patl + 16))       # one text chunk stays under 4 GiB
+        R = 2 * args.patl + 16
+        rec = torch.empty((nn, R), dtype=torch.uint8, device=dev)
+        idx = torch.arange(nn, device=dev, dtype=torch.int64)
+        rec[:, 0] = ord("@")
+        for d in range(10):
+            rec[:, 1 + d] = (48 + (idx // 10 ** (9 - d)) % 10).to(torch.uint8)
+        lut = torch.tensor([65, 67, 71, 84, 78], dtype=torch.uint8, device=dev)
+        P = args.patl
+        rec[:, 11] = 10
+        rec[:, 12:12 + P] = lut[bases[:nn * P].view(nn, P).long()]
+        rec[:, 12 + P] = 10; rec[:, 13 + P] = ord("+"); rec[:, 14 + P] = 10
+        rec[:, 15 + P:15 + 2 * P] = qual[:nn * P].view(nn, P) + 33
+        rec[:, 15 + 2 * P] = 10
+        text = rec.view(-1)
+        del idx
+        torch.cuda.synchronize()
+        p = m.parse_reads(text, fastq=True, quality_offset=33)                       # warm-up (allocations)
+        ok = (p.n_reads == nn and np.array_equal(m.download(p.bases, 10_000_000, np.uint8), bases[:10_000_000].cpu().numpy())
+              and np.array_equal(m.download(p.qual, 10_000_000, np.uint8), qual[:10_000_000].cpu().numpy()))
+        m.kernel_time(rlib.K_PARSE, reset=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            p = m.parse_reads(text, fastq=True, quality_offset=33)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        hinfo, hscore = m.match_unique_parsed(p)
+        st = (hinfo >> np.uint64(61)) & np.uint64(7)
+        print(json.dumps({"side_measurement": True, "mode": "ingest", "reads": nn, "text_bytes": int(text.numel()),
+                          "parse_ms": dt * 1e3, "parse_ms_by_hip_events": m.kernel_time(rlib.K_PARSE)[0] / max(m.kernel_time(rlib.K_PARSE)[1], 1),
+                          "reads_per_s": nn / dt, "text_GB_per_s": text.numel() / dt / 1e9,
+                          "hbm_bytes_algorithmic": int(text.numel()) + 2 * nn * P + 8 * nn, "parsed_equals_source_on_10M_symbols": bool(ok),
+                          "uniquely_aligned_frac_from_parsed": float(((st == 1) | (st == 2)).mean())}), flush=True)
+        return
 
     if args.mode == "all" or args.host_buffers:
         # manual side measurements (matchAll; host buffers): their own simple loop and JSON line

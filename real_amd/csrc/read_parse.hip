@@ -22,6 +22,78 @@ struct LenToU64 {
     __host__ __device__ uint64_t operator()(uint32_t v) const { return (uint64_t)v; }
 };
 
+// ---- newline positions: count per 16 KiB block, scan, fill (the text is read twice with 16-byte loads) ----
+#define NL_BLOCK_BYTES (256u * 16u * 4u)
+
+// bit 7 of every byte of x that equals '\n'
+__device__ __forceinline__ uint32_t nl_mask(uint32_t x)
+{
+    const uint32_t t = x ^ 0x0a0a0a0au;
+    return ~(((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t | 0x7f7f7f7fu);
+}
+// the 16 bytes at text + o (o a multiple of 16, text 16-byte aligned); bytes at or behind n_bytes read as 0
+__device__ __forceinline__ uint4 text16(const char *__restrict__ text, uint64_t o, uint64_t n_bytes)
+{
+    if (o + 16 <= n_bytes) return *reinterpret_cast<const uint4 *>(text + o);
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (uint64_t b = o; b < n_bytes; ++b) w[(b - o) >> 2] |= (uint32_t)(uint8_t)text[b] << (8 * ((b - o) & 3));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__global__ __launch_bounds__(256) void nl_count_kernel(const char *__restrict__ text, uint64_t n_bytes, uint32_t *__restrict__ block_count)
+{
+    __shared__ uint32_t part[4];
+    uint32_t c = 0;
+    const uint64_t base = (uint64_t)blockIdx.x * NL_BLOCK_BYTES;
+    for (int it = 0; it < 4; ++it) {
+        const uint64_t o = base + (uint64_t)it * 4096 + threadIdx.x * 16;
+        if (o < n_bytes) {
+            const uint4 v = text16(text, o, n_bytes);
+            c += __popc(nl_mask(v.x)) + __popc(nl_mask(v.y)) + __popc(nl_mask(v.z)) + __popc(nl_mask(v.w));
+        }
+    }
+    for (int d = 32; d; d >>= 1) c += __shfl_xor((int)c, d);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_count[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ __launch_bounds__(256) void nl_fill_kernel(const char *__restrict__ text, uint64_t n_bytes, const uint32_t *__restrict__ block_off,
+                                                      uint32_t *__restrict__ nl)
+{
+    __shared__ uint32_t wsum[4];
+    const uint64_t base = (uint64_t)blockIdx.x * NL_BLOCK_BYTES;
+    uint32_t run = block_off[blockIdx.x];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int it = 0; it < 4; ++it) {
+        const uint64_t o = base + (uint64_t)it * 4096 + threadIdx.x * 16;
+        uint32_t mk[4] = {0, 0, 0, 0};
+        if (o < n_bytes) {
+            const uint4 v = text16(text, o, n_bytes);
+            mk[0] = nl_mask(v.x); mk[1] = nl_mask(v.y); mk[2] = nl_mask(v.z); mk[3] = nl_mask(v.w);
+        }
+        const uint32_t c = __popc(mk[0]) + __popc(mk[1]) + __popc(mk[2]) + __popc(mk[3]);
+        // exclusive prefix of c over the 256 threads (= over the 4 KiB in byte order)
+        uint32_t incl = c;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up((int)incl, d); if (lane >= (uint32_t)d) incl += t; }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+        for (int w = 0; w < 4; ++w) { if ((uint32_t)w < wv) before += wsum[w]; total += wsum[w]; }
+        uint32_t at = run + before + incl - c;
+        for (int q = 0; q < 4; ++q) {
+            uint32_t mq = mk[q];
+            while (mq) {
+                const int bit = __ffs((int)mq) - 1; // bit 7 of byte bit/8
+                nl[at++] = (uint32_t)(o + 4 * q + (bit >> 3));
+                mq &= mq - 1;
+            }
+        }
+        run += total;
+        __syncthreads();
+    }
+}
+
 // start and length of line j of the chunk (without its '\n' and a '\r' in front of it); line m (after the last
 // newline) exists when the chunk does not end in a newline
 __device__ __forceinline__ void line_span(const char *__restrict__ text, const uint32_t *__restrict__ nl, uint64_t m, uint64_t n_bytes,
@@ -61,30 +133,38 @@ __global__ void record_spans_kernel(const char *__restrict__ text, const uint32_
     if ((threadIdx.x & 63) == 0 && mylen) atomicMax(max_len, mylen);
 }
 
-// one thread per record: symbols and qualities to their place in the batch arrays
-__global__ void record_gather_kernel(const char *__restrict__ text, uint64_t n_rec, const uint32_t *__restrict__ seq_start,
-                                     const uint32_t *__restrict__ qual_start, const uint64_t *__restrict__ off, int fastq, int qoff,
-                                     uint8_t *__restrict__ bases, uint8_t *__restrict__ qual, unsigned int *__restrict__ bad)
+// one wave per 64 records: their symbols and qualities go to one contiguous range of the batch arrays; the wave
+// walks its records one after the other and its lanes take consecutive bytes, so every load and store is a
+// coalesced run of the record's bytes
+__global__ __launch_bounds__(256) void record_gather_kernel(const char *__restrict__ text, uint64_t n_rec,
+                                                            const uint32_t *__restrict__ seq_start, const uint32_t *__restrict__ qual_start,
+                                                            const uint64_t *__restrict__ off, int fastq, int qoff, uint8_t *__restrict__ bases,
+                                                            uint8_t *__restrict__ qual, unsigned int *__restrict__ bad)
 {
-    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_rec) return;
-    const uint64_t o = off[r];
-    const uint32_t len = (uint32_t)(off[r + 1] - o);
-    const char *s = text + seq_start[r];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t r0 = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+    if (r0 >= n_rec) return;
+    const uint64_t r = r0 + lane;
+    const bool in = r < n_rec;
+    const uint64_t my_o = in ? off[r] : 0;
+    const uint32_t my_len = in ? (uint32_t)(off[r + 1] - my_o) : 0u;
+    const uint32_t my_s = in ? seq_start[r] : 0u, my_q = (in && fastq) ? qual_start[r] : 0u;
+    const uint32_t cnt = (uint32_t)min((uint64_t)64, n_rec - r0);
     bool space = false;
-    for (uint32_t i = 0; i < len; ++i) {
-        const char c = s[i];
-        uint8_t v;
-        switch (c) { case 'A': v = 0; break; case 'C': v = 1; break; case 'G': v = 2; break; case 'T': v = 3; break; default: v = 4; }
-        space = space || c == ' ' || (c >= '\t' && c <= '\r'); // isspace: the reference would skip it
-        bases[o + i] = v;
-    }
-    if (fastq) {
-        const char *q = text + qual_start[r];
-        for (uint32_t i = 0; i < len; ++i) {
-            const char c = q[i];
-            space = space || c == ' ' || (c >= '\t' && c <= '\r');
-            qual[o + i] = (uint8_t)(c - qoff);
+    for (uint32_t k = 0; k < cnt; ++k) {
+        const uint64_t o = __shfl(my_o, (int)k);
+        const uint32_t len = __shfl(my_len, (int)k), s = __shfl(my_s, (int)k), q = __shfl(my_q, (int)k);
+        for (uint32_t i = lane; i < len; i += 64) {
+            const char c = text[s + i];
+            uint8_t v;
+            switch (c) { case 'A': v = 0; break; case 'C': v = 1; break; case 'G': v = 2; break; case 'T': v = 3; break; default: v = 4; }
+            space = space || c == ' ' || (c >= '\t' && c <= '\r'); // isspace: the reference would skip it
+            bases[o + i] = v;
+            if (fastq) {
+                const char d = text[q + i];
+                space = space || d == ' ' || (d >= '\t' && d <= '\r');
+                qual[o + i] = (uint8_t)(d - qoff);
+            }
         }
     }
     if (space) atomicOr(bad, 4u);
@@ -103,7 +183,26 @@ int rh_parse_reads(real_hip_ctx *ctx, const char *d_text, uint64_t n_bytes, int 
     RH_HIP(ctx, hipMemsetAsync(ctx->p_scal.p, 0, 64, ctx->stream));
     size_t *d_count = (size_t *)ctx->p_scal.p;
     unsigned int *d_bad = (unsigned int *)((uint8_t *)ctx->p_scal.p + 16), *d_max = (unsigned int *)((uint8_t *)ctx->p_scal.p + 24);
-    {
+    if (((uintptr_t)d_text & 15) == 0) {
+        const uint64_t nblk = (n_bytes + NL_BLOCK_BYTES - 1) / NL_BLOCK_BYTES;
+        if ((rc = rh_reserve(ctx, ctx->p_len1, (nblk + 1) * 4 * 2))) return rc;
+        uint32_t *bc = (uint32_t *)ctx->p_len1.p, *bo = bc + nblk + 1;
+        hipLaunchKernelGGL(nl_count_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, d_text, n_bytes, bc);
+        RH_HIP(ctx, hipMemsetAsync(bc + nblk, 0, 4, ctx->stream));
+        size_t tmp = 0;
+        RH_HIP(ctx, rocprim::exclusive_scan(nullptr, tmp, bc, bo, 0u, (size_t)(nblk + 1), rocprim::plus<uint32_t>(), ctx->stream));
+        if ((rc = rh_reserve(ctx, ctx->sort_tmp, tmp ? tmp : 8))) return rc;
+        RH_HIP(ctx, rocprim::exclusive_scan(ctx->sort_tmp.p, tmp, bc, bo, 0u, (size_t)(nblk + 1), rocprim::plus<uint32_t>(), ctx->stream));
+        hipLaunchKernelGGL(nl_fill_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, d_text, n_bytes, (const uint32_t *)bo,
+                           (uint32_t *)ctx->p_nl.p);
+        // the count as a size_t where the generic path leaves it
+        uint32_t h_m = 0;
+        RH_HIP(ctx, hipMemcpyAsync(&h_m, bo + nblk, 4, hipMemcpyDeviceToHost, ctx->stream));
+        RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const size_t m64 = h_m;
+        RH_HIP(ctx, hipMemcpyAsync(d_count, &m64, sizeof(size_t), hipMemcpyHostToDevice, ctx->stream));
+        RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    } else { // (text at an odd address: generic compaction)
         IsNewline pred{d_text};
         size_t tmp = 0;
         RH_HIP(ctx, rocprim::select(nullptr, tmp, rocprim::counting_iterator<uint32_t>(0), (uint32_t *)ctx->p_nl.p, d_count,
@@ -151,7 +250,7 @@ int rh_parse_reads(real_hip_ctx *ctx, const char *d_text, uint64_t n_bytes, int 
     // 4. symbols and qualities
     if ((rc = rh_reserve(ctx, ctx->p_bases, total ? total : 1))) return rc;
     if (fastq && (rc = rh_reserve(ctx, ctx->p_qual, total ? total : 1))) return rc;
-    hipLaunchKernelGGL(record_gather_kernel, grid, block, 0, ctx->stream, d_text, n, (const uint32_t *)seq_start, (const uint32_t *)qual_start,
+    hipLaunchKernelGGL(record_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_text, n, (const uint32_t *)seq_start, (const uint32_t *)qual_start,
                        (const uint64_t *)ctx->p_off.p, fastq, qoff, (uint8_t *)ctx->p_bases.p, (uint8_t *)ctx->p_qual.p, d_bad);
     RH_HIP(ctx, hipGetLastError());
     RH_HIP(ctx, hipMemcpyAsync(h, d_bad, 16, hipMemcpyDeviceToHost, ctx->stream));

@@ -72,6 +72,19 @@ def test_parse_fastq_equals_generator(crlf, trail):
     m.close()
 
 
+def test_parse_device_text_at_odd_address():
+    import torch
+    g = synth.random_genome(50_000, seed=13)
+    b = synth.sample_reads(g, 2000, 100, 0.02, seed=14)
+    text = _fastq(b)
+    t = torch.frombuffer(bytearray(b"#" + text), dtype=torch.uint8).cuda()[1:]      # device pointer = base + 1
+    m = UniqueMatcher(_opts())
+    p = m.parse_reads(t, fastq=True, quality_offset=33)
+    _check(m, p, b)
+    assert np.array_equal(m.download(p.qual, int(p.n_symbols), np.uint8), b.qual)
+    m.close()
+
+
 def test_parse_fasta_and_lowercase():
     g = synth.random_genome(20_000, seed=5)
     b = synth.sample_reads(g, 500, 36, 0.0, seed=6)
