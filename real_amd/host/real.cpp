@@ -139,6 +139,43 @@ uint64_t nextBlock(const RealOptions &o, std::vector<std::unique_ptr<Ctx>> &ctx,
     return n;
 }
 
+// The read file as raw text, cut into chunks of whole records for real_hip_parse_reads: a chunk ends behind a
+// newline whose index is a multiple of the lines per record (4 FASTQ, 2 FASTA); only text in that form parses.
+class RawChunker {
+public:
+    RawChunker(const std::string &fn, bool fastq, size_t chunk_bytes) : lpr_(fastq ? 4 : 2), cap_(chunk_bytes)
+    {
+        f_ = fopen(fn.c_str(), "rb");
+        if (!f_) throw std::runtime_error("Unable to open pattern file.");
+    }
+    ~RawChunker() { if (f_) fclose(f_); }
+    // false at the end of the file; text = whole records
+    bool next(std::vector<char> &text)
+    {
+        text.swap(carry_);
+        carry_.clear();
+        const size_t have = text.size();
+        text.resize(cap_);
+        size_t got = eof_ ? 0 : fread(text.data() + have, 1, cap_ - have, f_);
+        if (have + got < cap_) eof_ = true;
+        text.resize(have + got);
+        if (text.empty()) return false;
+        if (eof_) return true; // the rest of the file (the parser accepts a last line without newline)
+        size_t lines = 0, cut = 0;
+        for (const char *p = text.data(), *e = p + text.size(); (p = (const char *)memchr(p, '\n', e - p)); ++p)
+            if (++lines % lpr_ == 0) cut = (size_t)(p - text.data()) + 1;
+        if (!cut) throw std::runtime_error("a read record longer than the text chunk");
+        carry_.assign(text.begin() + cut, text.end());
+        text.resize(cut);
+        return true;
+    }
+private:
+    FILE *f_ = nullptr;
+    size_t lpr_, cap_;
+    bool eof_ = false;
+    std::vector<char> carry_;
+};
+
 real_hip_batch makeBatch(const ReadBlock &b)
 {
     real_hip_batch rb;
@@ -177,9 +214,63 @@ int matchUnique(const RealOptions &o)
             const uint64_t n = nextBlock(o, ctx, R, first, n_list, have_next);
             if (!n) break;
             first += n;
+            uint64_t handled = 0;
+            bool parsed_on_device = false;
+            if (o.gpuparse) {
+                // f2: the file goes to the device as text; one chunk per context and round.  Text that is not in
+                // one-line-per-field form is refused by the library and read by the host reader below.
+                RawChunker rc(o.patternfilename, o.fastq, (size_t)256 << 20);
+                std::vector<std::vector<char>> txt(ctx.size());
+                uint64_t next_id = 0;
+                parsed_on_device = true;
+                while (parsed_on_device) {
+                    size_t used = 0;
+                    for (; used < ctx.size(); ++used)
+                        if (!rc.next(txt[used])) break;
+                    if (!used) break;
+                    std::vector<real_hip_parsed> pr(used);
+                    std::vector<int> prc(used, 0);
+                    {
+                        std::vector<std::thread> th;
+                        for (size_t g = 0; g < used; ++g)
+                            th.emplace_back([&, g]() {
+                                prc[g] = real_hip_parse_reads(ctx[g]->h, txt[g].data(), txt[g].size(), 0, o.fastq ? 1 : 0, qoff, &pr[g]);
+                            });
+                        for (auto &t : th) t.join();
+                    }
+                    for (size_t g = 0; g < used; ++g) {
+                        if (prc[g] == REAL_HIP_E_UNSUPPORTED && handled == 0) { parsed_on_device = false; break; }
+                        check(ctx[g]->h, prc[g], "real_hip_parse_reads");
+                    }
+                    if (!parsed_on_device) break;
+                    std::vector<uint64_t> first(used);
+                    for (size_t g = 0; g < used; ++g) { first[g] = next_id; next_id += pr[g].n_reads; }
+                    if (next_id > numpat) throw std::runtime_error("device parser found more reads than countPatterns");
+                    std::vector<std::thread> th;
+                    std::vector<std::string> errs(used);
+                    for (size_t g = 0; g < used; ++g)
+                        th.emplace_back([&, g]() {
+                            try {
+                                real_hip_batch rb;
+                                memset(&rb, 0, sizeof rb);
+                                rb.struct_size = sizeof rb; rb.on_device = 2; rb.n_reads = pr[g].n_reads;
+                                rb.bases = pr[g].bases; rb.qual = pr[g].qual; rb.offsets = pr[g].offsets; rb.max_patl = pr[g].max_patl;
+                                if (rb.n_reads)
+                                    check(ctx[g]->h, real_hip_match_unique(ctx[g]->h, &rb, info.data() + first[g],
+                                                                           o.scores ? score.data() + first[g] : nullptr),
+                                          "real_hip_match_unique");
+                            } catch (const std::exception &e) { errs[g] = e.what(); }
+                        });
+                    for (auto &t : th) t.join();
+                    for (auto &e : errs) if (!e.empty()) throw std::runtime_error(e);
+                    handled = next_id;
+                    std::cerr << "\r                                                              \r" << (double)handled / (numpat ? numpat : 1) << std::flush;
+                }
+                if (parsed_on_device && handled != numpat) throw std::runtime_error("device parser and countPatterns disagree on the number of reads");
+            }
+            if (!parsed_on_device) {
             ReadReader rr(o.patternfilename, o.fastq, qoff);     // the whole read set is re-streamed per block, :1260
             std::vector<ReadBlock> blk(ctx.size());
-            uint64_t handled = 0;
             while (true) {
                 size_t used = 0;
                 for (; used < ctx.size(); ++used)
@@ -200,6 +291,7 @@ int matchUnique(const RealOptions &o)
                 for (auto &e : errs) if (!e.empty()) throw std::runtime_error(e);
                 for (size_t g = 0; g < used; ++g) handled += blk[g].size();
                 std::cerr << "\r                                                              \r" << (double)handled / (numpat ? numpat : 1) << std::flush;
+            }
             }
             std::cerr << std::endl;
         }

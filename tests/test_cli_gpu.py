@@ -66,12 +66,18 @@ def oracle_unique(ora, g, b, seedl, seedk, totalk, scores, n_list=0, fasta=False
     (1, ["-index", "host", "-T", "3"], 0, True),
     (1, ["-block", "30000", "-batch", "500"], 30000, True),      # three index blocks, several read batches
     (1, [], 0, False),                                             # FASTA reads: constant quality 30
+    (1, ["-gpuparse", "0"], 0, True),                              # read file parsed by the host reader
+    (1, ["-wrap"], 0, False),                                      # wrapped FASTA: the device parser refuses, host reader takes over
 ])
 def test_real_cli_match_unique(ora, tmp_path, scores, extra, n_list, fastq):
     g = synth.random_genome(80_000, seed=41, n_frag=3, n_runs=6, repeats=15)
     b = synth.concat_batches([synth.sample_reads(g, 1500, 100, 0.02, seed=42, n_read_prob=0.0005),
                               synth.sample_reads(g, 300, 60, 0.02, seed=43)])
     fa, rd = write_inputs(tmp_path, g, b, fastq)
+    if "-wrap" in extra:                                           # every sequence line cut in two (FastAReader.hpp:107-138 joins them)
+        extra = []
+        lines = open(rd).read().split("\n")
+        open(rd, "w").write("\n".join(l if l.startswith(">") or not l else l[:37] + "\n" + l[37:] for l in lines))
     out = str(tmp_path / "out.tsv")
     cmd = [REAL, "-t", fa, "-p", rd, "-o", out, "-e", "3", "-s", "2", "-l", "32", "-q", str(scores)] + extra
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
