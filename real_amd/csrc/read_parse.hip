@@ -40,18 +40,28 @@ __device__ __forceinline__ uint4 text16(const char *__restrict__ text, uint64_t 
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-__global__ __launch_bounds__(256) void nl_count_kernel(const char *__restrict__ text, uint64_t n_bytes, uint32_t *__restrict__ block_count)
+// bit 7 of every byte of x that equals '\r'
+__device__ __forceinline__ uint32_t cr_mask(uint32_t x)
+{
+    const uint32_t t = x ^ 0x0d0d0d0du;
+    return ~(((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t | 0x7f7f7f7fu);
+}
+
+__global__ __launch_bounds__(256) void nl_count_kernel(const char *__restrict__ text, uint64_t n_bytes, uint32_t *__restrict__ block_count,
+                                                       unsigned int *__restrict__ any_cr)
 {
     __shared__ uint32_t part[4];
-    uint32_t c = 0;
+    uint32_t c = 0, cr = 0;
     const uint64_t base = (uint64_t)blockIdx.x * NL_BLOCK_BYTES;
     for (int it = 0; it < 4; ++it) {
         const uint64_t o = base + (uint64_t)it * 4096 + threadIdx.x * 16;
         if (o < n_bytes) {
             const uint4 v = text16(text, o, n_bytes);
             c += __popc(nl_mask(v.x)) + __popc(nl_mask(v.y)) + __popc(nl_mask(v.z)) + __popc(nl_mask(v.w));
+            cr |= cr_mask(v.x) | cr_mask(v.y) | cr_mask(v.z) | cr_mask(v.w);
         }
     }
+    if (__any(cr != 0) && (threadIdx.x & 63) == 0) atomicOr(any_cr, 1u);
     for (int d = 32; d; d >>= 1) c += __shfl_xor((int)c, d);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
     __syncthreads();
@@ -97,40 +107,42 @@ __global__ __launch_bounds__(256) void nl_fill_kernel(const char *__restrict__ t
 // start and length of line j of the chunk (without its '\n' and a '\r' in front of it); line m (after the last
 // newline) exists when the chunk does not end in a newline
 __device__ __forceinline__ void line_span(const char *__restrict__ text, const uint32_t *__restrict__ nl, uint64_t m, uint64_t n_bytes,
-                                          uint64_t j, uint32_t &start, uint32_t &len)
+                                          bool has_cr, uint64_t j, uint32_t &start, uint32_t &len)
 {
     const uint32_t s = j ? nl[j - 1] + 1 : 0u;
     uint32_t e = j < m ? nl[j] : (uint32_t)n_bytes;
-    if (e > s && text[e - 1] == '\r') e--;
+    if (has_cr && e > s && text[e - 1] == '\r') e--; // (no '\r' anywhere in the chunk: nothing to look at)
     start = s; len = e - s;
 }
 
 // one thread per record: field spans, form check, length
 __global__ void record_spans_kernel(const char *__restrict__ text, const uint32_t *__restrict__ nl, uint64_t m, uint64_t n_bytes,
-                                    uint64_t n_rec, int fastq, uint32_t *__restrict__ seq_start, uint32_t *__restrict__ seq_len,
+                                    uint64_t n_rec, int fastq, const unsigned int *__restrict__ any_cr, uint32_t *__restrict__ seq_start, uint32_t *__restrict__ seq_len,
                                     uint32_t *__restrict__ qual_start, uint32_t *__restrict__ id_start, uint32_t *__restrict__ id_len,
                                     unsigned int *__restrict__ bad, unsigned int *__restrict__ max_len)
 {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t mylen = 0;
+    const bool has_cr = *any_cr != 0;
     if (r < n_rec) {
         const uint64_t l0 = r * (fastq ? 4 : 2);
         uint32_t s, l;
-        line_span(text, nl, m, n_bytes, l0, s, l);
+        line_span(text, nl, m, n_bytes, has_cr, l0, s, l);
         if (l == 0 || text[s] != (fastq ? '@' : '>')) atomicOr(bad, 1u);
         id_start[r] = s + 1; id_len[r] = l ? l - 1 : 0;
-        line_span(text, nl, m, n_bytes, l0 + 1, s, l);
+        line_span(text, nl, m, n_bytes, has_cr, l0 + 1, s, l);
         seq_start[r] = s; seq_len[r] = l; mylen = l;
         if (fastq) {
             uint32_t ps, pl, qs, ql;
-            line_span(text, nl, m, n_bytes, l0 + 2, ps, pl);
-            line_span(text, nl, m, n_bytes, l0 + 3, qs, ql);
+            line_span(text, nl, m, n_bytes, has_cr, l0 + 2, ps, pl);
+            line_span(text, nl, m, n_bytes, has_cr, l0 + 3, qs, ql);
             if (pl == 0 || text[ps] != '+' || ql != l) atomicOr(bad, 2u);
             qual_start[r] = qs;
         }
     }
     for (int d = 32; d; d >>= 1) mylen = max(mylen, (uint32_t)__shfl_xor((int)mylen, d));
-    if ((threadIdx.x & 63) == 0 && mylen) atomicMax(max_len, mylen);
+    // (one atomic per wave onto one address serialises the kernel: only a wave that can raise the maximum issues it)
+    if ((threadIdx.x & 63) == 0 && mylen > *(volatile unsigned int *)max_len) atomicMax(max_len, mylen);
 }
 
 // one wave per 64 records: their symbols and qualities go to one contiguous range of the batch arrays; the wave
@@ -151,20 +163,32 @@ __global__ __launch_bounds__(256) void record_gather_kernel(const char *__restri
     const uint32_t my_s = in ? seq_start[r] : 0u, my_q = (in && fastq) ? qual_start[r] : 0u;
     const uint32_t cnt = (uint32_t)min((uint64_t)64, n_rec - r0);
     bool space = false;
-    for (uint32_t k = 0; k < cnt; ++k) {
-        const uint64_t o = __shfl(my_o, (int)k);
-        const uint32_t len = __shfl(my_len, (int)k), s = __shfl(my_s, (int)k), q = __shfl(my_q, (int)k);
-        for (uint32_t i = lane; i < len; i += 64) {
-            const char c = text[s + i];
+    // work items = (record of the wave, 64-byte chunk of it); four items' loads are in flight before their stores
+    uint32_t maxlen = my_len;
+    for (int d = 32; d; d >>= 1) maxlen = max(maxlen, (uint32_t)__shfl_xor((int)maxlen, d));
+    const uint32_t chunks = (maxlen + 63) >> 6, items = cnt * chunks;
+    for (uint32_t t0 = 0; t0 < items; t0 += 4) {
+        char c[4], d[4];
+        uint64_t dst[4];
+        bool on[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t t = t0 + u, k = min(t / chunks, cnt - 1), i = (t % chunks) * 64 + lane;
+            const uint64_t o = __shfl(my_o, (int)k);
+            const uint32_t len = __shfl(my_len, (int)k), sk = __shfl(my_s, (int)k), qk = __shfl(my_q, (int)k);
+            on[u] = t < items && i < len;
+            dst[u] = o + i;
+            c[u] = on[u] ? text[sk + i] : 'A';
+            d[u] = (on[u] && fastq) ? text[qk + i] : '!';
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!on[u]) continue;
             uint8_t v;
-            switch (c) { case 'A': v = 0; break; case 'C': v = 1; break; case 'G': v = 2; break; case 'T': v = 3; break; default: v = 4; }
-            space = space || c == ' ' || (c >= '\t' && c <= '\r'); // isspace: the reference would skip it
-            bases[o + i] = v;
-            if (fastq) {
-                const char d = text[q + i];
-                space = space || d == ' ' || (d >= '\t' && d <= '\r');
-                qual[o + i] = (uint8_t)(d - qoff);
-            }
+            switch (c[u]) { case 'A': v = 0; break; case 'C': v = 1; break; case 'G': v = 2; break; case 'T': v = 3; break; default: v = 4; }
+            space = space || c[u] == ' ' || (c[u] >= '\t' && c[u] <= '\r') || d[u] == ' ' || (d[u] >= '\t' && d[u] <= '\r'); // isspace: the reference would skip it
+            bases[dst[u]] = v;
+            if (fastq) qual[dst[u]] = (uint8_t)(d[u] - qoff);
         }
     }
     if (space) atomicOr(bad, 4u);
@@ -183,11 +207,14 @@ int rh_parse_reads(real_hip_ctx *ctx, const char *d_text, uint64_t n_bytes, int 
     RH_HIP(ctx, hipMemsetAsync(ctx->p_scal.p, 0, 64, ctx->stream));
     size_t *d_count = (size_t *)ctx->p_scal.p;
     unsigned int *d_bad = (unsigned int *)((uint8_t *)ctx->p_scal.p + 16), *d_max = (unsigned int *)((uint8_t *)ctx->p_scal.p + 24);
+    unsigned int *d_cr = (unsigned int *)((uint8_t *)ctx->p_scal.p + 32);
+    size_t m = 0;
+    char last = 0;
     if (((uintptr_t)d_text & 15) == 0) {
         const uint64_t nblk = (n_bytes + NL_BLOCK_BYTES - 1) / NL_BLOCK_BYTES;
         if ((rc = rh_reserve(ctx, ctx->p_len1, (nblk + 1) * 4 * 2))) return rc;
         uint32_t *bc = (uint32_t *)ctx->p_len1.p, *bo = bc + nblk + 1;
-        hipLaunchKernelGGL(nl_count_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, d_text, n_bytes, bc);
+        hipLaunchKernelGGL(nl_count_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, d_text, n_bytes, bc, d_cr);
         RH_HIP(ctx, hipMemsetAsync(bc + nblk, 0, 4, ctx->stream));
         size_t tmp = 0;
         RH_HIP(ctx, rocprim::exclusive_scan(nullptr, tmp, bc, bo, 0u, (size_t)(nblk + 1), rocprim::plus<uint32_t>(), ctx->stream));
@@ -195,14 +222,14 @@ int rh_parse_reads(real_hip_ctx *ctx, const char *d_text, uint64_t n_bytes, int 
         RH_HIP(ctx, rocprim::exclusive_scan(ctx->sort_tmp.p, tmp, bc, bo, 0u, (size_t)(nblk + 1), rocprim::plus<uint32_t>(), ctx->stream));
         hipLaunchKernelGGL(nl_fill_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, d_text, n_bytes, (const uint32_t *)bo,
                            (uint32_t *)ctx->p_nl.p);
-        // the count as a size_t where the generic path leaves it
         uint32_t h_m = 0;
         RH_HIP(ctx, hipMemcpyAsync(&h_m, bo + nblk, 4, hipMemcpyDeviceToHost, ctx->stream));
+        RH_HIP(ctx, hipMemcpyAsync(&last, d_text + n_bytes - 1, 1, hipMemcpyDeviceToHost, ctx->stream));
         RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        const size_t m64 = h_m;
-        RH_HIP(ctx, hipMemcpyAsync(d_count, &m64, sizeof(size_t), hipMemcpyHostToDevice, ctx->stream));
-        RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    } else { // (text at an odd address: generic compaction)
+        m = h_m;
+    } else { // (text at an odd address: generic compaction; '\r' is then looked for at every line end)
+        const unsigned int one = 1;
+        RH_HIP(ctx, hipMemcpyAsync(d_cr, &one, 4, hipMemcpyHostToDevice, ctx->stream));
         IsNewline pred{d_text};
         size_t tmp = 0;
         RH_HIP(ctx, rocprim::select(nullptr, tmp, rocprim::counting_iterator<uint32_t>(0), (uint32_t *)ctx->p_nl.p, d_count,
@@ -210,12 +237,10 @@ int rh_parse_reads(real_hip_ctx *ctx, const char *d_text, uint64_t n_bytes, int 
         if ((rc = rh_reserve(ctx, ctx->sort_tmp, tmp ? tmp : 8))) return rc;
         RH_HIP(ctx, rocprim::select(ctx->sort_tmp.p, tmp, rocprim::counting_iterator<uint32_t>(0), (uint32_t *)ctx->p_nl.p, d_count,
                                     (size_t)n_bytes, pred, ctx->stream));
+        RH_HIP(ctx, hipMemcpyAsync(&m, d_count, sizeof(size_t), hipMemcpyDeviceToHost, ctx->stream));
+        RH_HIP(ctx, hipMemcpyAsync(&last, d_text + n_bytes - 1, 1, hipMemcpyDeviceToHost, ctx->stream));
+        RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
-    size_t m = 0;
-    char last = 0;
-    RH_HIP(ctx, hipMemcpyAsync(&m, d_count, sizeof(size_t), hipMemcpyDeviceToHost, ctx->stream));
-    RH_HIP(ctx, hipMemcpyAsync(&last, d_text + n_bytes - 1, 1, hipMemcpyDeviceToHost, ctx->stream));
-    RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const uint64_t lines = m + (last == '\n' ? 0 : 1);
     const uint64_t lpr = fastq ? 4 : 2;
     if (lines % lpr) return rh_fail(ctx, REAL_HIP_E_UNSUPPORTED, "text is not whole records of one line per field", hipSuccess);
@@ -227,7 +252,7 @@ int rh_parse_reads(real_hip_ctx *ctx, const char *d_text, uint64_t n_bytes, int 
     if ((rc = rh_reserve(ctx, ctx->p_off, (n + 1) * 8))) return rc;
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
     hipLaunchKernelGGL(record_spans_kernel, grid, block, 0, ctx->stream, d_text, (const uint32_t *)ctx->p_nl.p, (uint64_t)m, n_bytes, n,
-                       fastq, seq_start, seq_len, qual_start, id_start, id_len, d_bad, d_max);
+                       fastq, (const unsigned int *)d_cr, seq_start, seq_len, qual_start, id_start, id_len, d_bad, d_max);
     // 3. offsets = exclusive scan of the lengths (n + 1 values: the last is the total)
     {
         if ((rc = rh_reserve(ctx, ctx->p_len1, (n + 1) * 4))) return rc;
