@@ -127,6 +127,7 @@ def main():
     ap.add_argument("--totalk", type=int, default=3)
     ap.add_argument("--scores", type=int, default=1)
     ap.add_argument("--prefix-bits", type=int, default=0)
+    ap.add_argument("--table-kind", type=int, default=0, help="device bucket tables: 0 auto, 1 starts, 2 directory, 3 bucket rows (real_hip.h)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--mode", choices=["unique", "all", "ingest"], default="unique",
@@ -163,7 +164,7 @@ def main():
     t_setup = time.time()
     sym = gen_genome(torch, G, 3, dev)                       # i.i.d. uniform ACGT, one fragment, seed 3
     frag = np.array([0, G], dtype=np.uint64)
-    m = (UniqueMatcher if args.mode == "unique" else AllMatcher)(opts, device=local, prefix_bits=args.prefix_bits)
+    m = (UniqueMatcher if args.mode == "unique" else AllMatcher)(opts, device=local, prefix_bits=args.prefix_bits, table_kind=args.table_kind)
     torch.cuda.synchronize()
     log("genome generated")
     m.set_text_symbols(0, sym, frag)
@@ -329,12 +330,12 @@ def main():
                                                                                args.totalk, "on" if args.scores else "off", world),
                        "genome_bp": G, "reads_per_gpu_per_step": n, "read_len": args.patl, "seedl": args.seedl,
                        "seedkmax": 2, "totalkmax": args.totalk, "scores": bool(args.scores), "errprob": 0.02,
-                       "index_entries": n_entries, "prefix_bits": m.prefix_bits, "bucket_tables": ("starts", "digest", "fingerprint")[m.table_kind],
+                       "index_entries": n_entries, "prefix_bits": m.prefix_bits, "bucket_tables": ("starts", "digest", "fingerprint", "rows")[m.table_kind],
                        "parallelism": "reads sharded x%d, index replicated, one RCCL gather of records" % world,
                        "uniquely_aligned_frac_rank0": aligned / n, "index_build_s": t_index, "setup_s": t_setup},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "match_kernel<W=%d,scores=%d,unique,tables=%s>" % ((args.patl + 31) // 32, args.scores, ("starts", "digest", "fingerprint")[m.table_kind]), "avg_launch_ms": avg_ms, "launches": match_n,
+                         "kernel": "match_kernel<W=%d,scores=%d,unique,tables=%s>" % ((args.patl + 31) // 32, args.scores, ("starts", "digest", "fingerprint", "rows")[m.table_kind]), "avg_launch_ms": avg_ms, "launches": match_n,
                          "algorithmic_bytes_per_read": a_total / max(ctr["reads"], 1),
                          "repeat_pass_avg_ms": rep_ms / max(rep_n, 1),
                          "work_per_read": {k: ctr[k] / max(ctr["reads"], 1) for k in ("lookups", "probes", "candidates", "seedpass", "hits", "verified")}},

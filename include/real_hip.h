@@ -59,7 +59,9 @@ typedef struct real_hip_params {
     int32_t  device;        /* HIP device ordinal                                     */
     uint32_t table_kind;    /* device bucket tables: 0 = auto from index size, 1 = bucket starts only,
                                2 = directory entries (group sizes + partner digests for seedl <= 32,
-                               key fingerprints for wider signatures); a host-layout detail like
+                               key fingerprints for wider signatures), 3 = bucket rows (seedl <= 32: one 128-byte
+                               row per bucket holds directory and entries, lookups by groups of eight
+                               lanes); a host-layout detail like
                                prefix_bits, results do not depend on it                   */
     double   filter_mult;   /* RealOptions.cpp:455-463; epsilon=(float)(filter_mult*patl),
                                RealOptions.hpp:74-77, matchUniqueImplementation.cpp:405 */
@@ -113,7 +115,7 @@ int real_hip_build_index_block(real_hip_ctx *ctx, uint64_t first_window, uint64_
                                uint64_t *n_entries, int *have_next);
 /* introspection (tests, CPU baseline): device layout of list k               */
 int real_hip_index_info(const real_hip_ctx *ctx, uint64_t *n_entries, uint32_t *prefix_bits);
-/* kind of the resident bucket tables: 0 bucket starts, 1 group sizes + partner digests, 2 key fingerprints */
+/* kind of the resident bucket tables: 0 bucket starts, 1 group sizes + partner digests, 2 key fingerprints, 3 bucket rows */
 int real_hip_index_table_kind(const real_hip_ctx *ctx, uint32_t *kind);
 int real_hip_index_download(real_hip_ctx *ctx, int list,
                             uint32_t *entries      /* n_entries x {key, pos} (raw device layout), nullable */,

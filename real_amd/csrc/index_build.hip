@@ -110,6 +110,13 @@ void rh_choose_tables(real_hip_ctx *ctx, uint64_t n_entries)
             if (pb < 8) pb = 8;
         }
     }
+    if (want == 3 && auto_pb && l <= 32) {
+        // bucket rows: about 11 entries per 128-byte row of 20, at most 16 signature values per row
+        pb = 1;
+        while (pb < 30 && (double)n_entries / (double)(1ull << pb) > 11.5) pb++;
+        if (pb + 4 < l) pb = l - 4;
+        if (pb + 1 > l) pb = l > 1 ? l - 1 : 1;
+    }
     if (pb > l) pb = l; // a signature has seedl bits (two segments of seedl/4 bases)
     if (pb > 30) pb = 30;
     if (pb < 1) pb = 1;
@@ -117,6 +124,7 @@ void rh_choose_tables(real_hip_ctx *ctx, uint64_t n_entries)
     uint32_t pshift, fshift, fbits, pbits;
     rh_index_geometry(l, pb, &pshift, &fshift, &fbits, &pbits);
     if (want == 1) ctx->fine = 0;
+    else if (want == 3 && l <= 32 && l >= pb && l - pb >= 1 && l - pb <= 4) ctx->fine = 3;
     else if (rh_is_fine(l, pb)) ctx->fine = 1;
     else if (pbits == 0 && (want == 2 || (auto_pb && big))) ctx->fine = 2;
     else ctx->fine = 0;
@@ -229,6 +237,146 @@ __global__ void fp_table_kernel(const uint32_t *__restrict__ bkt, const uint2 *_
     out[p] = make_uint4(start, (uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi);
 }
 
+// ---------------------------------------------------------------------------
+// bucket rows (table kind 3): one 128-byte row per bucket holds the directory AND the entries, so that a
+// lookup is ONE line of HBM, fetched by eight lanes with one coalesced request (match_lists_rows).
+//   simple bucket (at most RH_ROW_CAP entries, every key group at most 15):
+//     u64  sixteen 4-bit counts, nibble g = entries of key group g (= signature value g of the bucket)
+//     then the entries in list order, 6 bytes each: u16 leading partner-signature bits, u32 position
+//   complex bucket: u64 all ones, u32 first entry in the overflow array, u32 entries, sixteen u8 group counts
+//     (255 = "255 or more": bounds by binary search); its entries live in the overflow array as {key, pos}
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void bucket_groups(const uint2 *__restrict__ ent, uint32_t start, uint32_t end, uint32_t pbits, uint32_t gmask,
+                                              uint32_t cnt[16])
+{
+#pragma unroll
+    for (int g = 0; g < 16; ++g) cnt[g] = 0;
+    for (uint32_t j = start; j < end; ++j) {
+        const uint32_t k = (ent[j].x >> pbits) & gmask;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) if (k == (uint32_t)g) cnt[g]++;
+    }
+}
+
+__global__ void rows_overflow_kernel(const uint32_t *__restrict__ bkt, const uint2 *__restrict__ ent, uint64_t nbuckets, uint32_t pbits,
+                                     uint32_t fbits, uint32_t *__restrict__ ovf_cnt)
+{
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > nbuckets) return;
+    uint32_t out = 0;
+    if (p < nbuckets) {
+        const uint32_t start = bkt[p], end = bkt[p + 1], c = end - start;
+        bool complex_ = c > RH_ROW_CAP;
+        if (!complex_ && c > 15) {
+            uint32_t cnt[16];
+            bucket_groups(ent, start, end, pbits, (1u << fbits) - 1, cnt);
+#pragma unroll
+            for (int g = 0; g < 16; ++g) complex_ = complex_ || cnt[g] > 15;
+        }
+        out = complex_ ? c : 0u;
+    }
+    ovf_cnt[p] = out;
+}
+
+__global__ void rows_fill_kernel(const uint32_t *__restrict__ bkt, const uint2 *__restrict__ ent, uint64_t nbuckets, uint32_t pbits,
+                                 uint32_t fbits, const uint32_t *__restrict__ ovf_start, uint4 *__restrict__ rows, uint2 *__restrict__ ovf)
+{
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nbuckets) return;
+    const uint32_t start = bkt[p], end = bkt[p + 1], c = end - start;
+    const uint32_t os = ovf_start[p], oc = ovf_start[p + 1] - os;
+    uint32_t w[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) w[i] = 0;
+    uint32_t cnt[16];
+    bucket_groups(ent, start, end, pbits, (1u << fbits) - 1, cnt);
+    if (oc) { // complex
+        w[0] = w[1] = 0xffffffffu;
+        w[2] = os; w[3] = c;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) w[4 + (g >> 2)] |= (cnt[g] < 255 ? cnt[g] : 255u) << (8 * (g & 3));
+        for (uint32_t j = 0; j < c; ++j) ovf[os + j] = ent[start + j];
+    } else {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) w[g >> 3] |= cnt[g] << (4 * (g & 7));
+        const uint32_t p16 = pbits < 16 ? pbits : 16;
+        const uint32_t pmask = pbits ? ((1u << pbits) - 1) : 0u;
+        for (uint32_t j = 0; j < c; ++j) {
+            const uint2 e = ent[start + j];
+            const uint32_t key = (e.x & pmask) >> (pbits - p16);
+            // 6 bytes at byte 8 + 6j: halfwords 4+3j (key), 5+3j (pos low), 6+3j (pos high)
+            const uint32_t hw[3] = {key & 0xffffu, e.y & 0xffffu, e.y >> 16};
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const uint32_t h = 4 + 3 * j + t;
+                const uint32_t v = hw[t] << (16 * (h & 1));
+#pragma unroll
+                for (int i = 2; i < 32; ++i) if ((h >> 1) == (uint32_t)i) w[i] |= v;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rows[p * 8 + i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+
+// ordered traversal of the rows: per-bucket sizes, then (after a scan) the entries in list order
+__global__ void rows_sizes_kernel(const uint4 *__restrict__ rows, uint64_t nbuckets, uint32_t *__restrict__ size)
+{
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > nbuckets) return;
+    uint32_t c = 0;
+    if (p < nbuckets) {
+        const uint4 h = rows[p * 8];
+        if (h.x == 0xffffffffu && h.y == 0xffffffffu) c = h.w;
+        else {
+            const uint64_t hd = (uint64_t)h.x | ((uint64_t)h.y << 32);
+            for (int g = 0; g < 16; ++g) c += (uint32_t)(hd >> (4 * g)) & 15u;
+        }
+    }
+    size[p] = c;
+}
+__global__ void rows_unpack_kernel(const uint4 *__restrict__ rows, const uint2 *__restrict__ ovf, uint64_t nbuckets,
+                                   const uint32_t *__restrict__ off, uint2 *__restrict__ out)
+{
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nbuckets) return;
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(rows + p * 8);
+    const uint32_t o = off[p], c = off[p + 1] - o;
+    if (w[0] == 0xffffffffu && w[1] == 0xffffffffu) {
+        for (uint32_t j = 0; j < c; ++j) out[o + j] = ovf[w[2] + j];
+    } else {
+        const uint16_t *hw = reinterpret_cast<const uint16_t *>(w);
+        for (uint32_t j = 0; j < c; ++j)
+            out[o + j] = make_uint2(hw[4 + 3 * j], (uint32_t)hw[5 + 3 * j] | ((uint32_t)hw[6 + 3 * j] << 16));
+    }
+}
+
+// entries of list `list` in list order as {key, pos} (key = the row's 16 partner bits, or the overflow entry's key) and the
+// bucket starts; either output may be null.  Used by index_download / index_export.
+int rh_rows_unpack(real_hip_ctx *ctx, int list, uint2 *d_entries, uint32_t *d_starts)
+{
+    const uint64_t nb = 1ull << ctx->pb;
+    int rc;
+    DevBuf sizes, offs;
+    if ((rc = rh_reserve(ctx, sizes, (nb + 1) * 4))) return rc;
+    if ((rc = rh_reserve(ctx, offs, (nb + 1) * 4))) { rh_release(sizes); return rc; }
+    hipLaunchKernelGGL(rows_sizes_kernel, dim3((unsigned)((nb + 1 + 255) / 256)), dim3(256), 0, ctx->stream, (const uint4 *)ctx->bkt[list].p,
+                       nb, (uint32_t *)sizes.p);
+    size_t tmp = 0;
+    hipError_t e = rocprim::exclusive_scan(nullptr, tmp, (uint32_t *)sizes.p, (uint32_t *)offs.p, 0u, (size_t)(nb + 1), rocprim::plus<uint32_t>(), ctx->stream);
+    if (e == hipSuccess && !(rc = rh_reserve(ctx, ctx->sort_tmp, tmp ? tmp : 8)))
+        e = rocprim::exclusive_scan(ctx->sort_tmp.p, tmp, (uint32_t *)sizes.p, (uint32_t *)offs.p, 0u, (size_t)(nb + 1), rocprim::plus<uint32_t>(), ctx->stream);
+    if (e == hipSuccess && !rc && d_entries)
+        hipLaunchKernelGGL(rows_unpack_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, ctx->stream, (const uint4 *)ctx->bkt[list].p,
+                           (const uint2 *)ctx->ent[list].p, nb, (const uint32_t *)offs.p, d_entries);
+    if (e == hipSuccess && !rc && d_starts) e = hipMemcpyAsync(d_starts, offs.p, (nb + 1) * 4, hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    rh_release(sizes); rh_release(offs);
+    if (rc) return rc;
+    if (e != hipSuccess) return rh_fail(ctx, REAL_HIP_E_DEVICE, "rows unpack", e);
+    return REAL_HIP_OK;
+}
+
 int rh_index_from_sorted(real_hip_ctx *ctx, int list, const void *d_sign, const uint32_t *d_pos, uint64_t n,
                          unsigned sig_bytes)
 {
@@ -238,12 +386,13 @@ int rh_index_from_sorted(real_hip_ctx *ctx, int list, const void *d_sign, const 
     const uint32_t nb = 1u << pb;
     int rc = rh_reserve(ctx, ctx->ent[list], (n ? n : 1) * sizeof(uint2));
     if (rc) return rc;
-    if (ctx->fine) rh_release(ctx->bkt[list]); // holds a uint4 table from the previous block
+    if (ctx->fine) rh_release(ctx->bkt[list]); // holds a uint4 table / the rows of the previous block
     rc = rh_reserve(ctx, ctx->bkt[list], ((size_t)nb + 1) * 4);
     if (rc) return rc;
     if (!n) {
-        if (ctx->fine && (rc = rh_reserve(ctx, ctx->bkt[list], ((size_t)nb + 1) * 16))) return rc;
-        RH_HIP(ctx, hipMemsetAsync(ctx->bkt[list].p, 0, ((size_t)nb + 1) * (ctx->fine ? 16 : 4), ctx->stream));
+        const size_t esz = ctx->fine == 3 ? 128 : (ctx->fine ? 16 : 4);
+        if (ctx->fine && (rc = rh_reserve(ctx, ctx->bkt[list], ((size_t)nb + 1) * esz))) return rc;
+        RH_HIP(ctx, hipMemsetAsync(ctx->bkt[list].p, 0, ((size_t)nb + 1) * esz, ctx->stream));
         return REAL_HIP_OK;
     }
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
@@ -255,6 +404,34 @@ int rh_index_from_sorted(real_hip_ctx *ctx, int list, const void *d_sign, const 
         hipLaunchKernelGGL(entries_kernel<uint64_t>, grid, block, 0, ctx->stream, (const uint64_t *)d_sign, d_pos, n, l, list, T,
                            pshift, fshift, fbits, pbits, nb, (uint2 *)ctx->ent[list].p, (uint32_t *)ctx->bkt[list].p);
     RH_HIP(ctx, hipGetLastError());
+    if (ctx->fine == 3) {
+        // rows: overflow sizes, scan, fill; then the full entry array and the bucket starts are dropped
+        RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        rh_release(ctx->keys_b); rh_release(ctx->vals_b); // (device build: the sorted inputs are in ent now)
+        DevBuf ocnt, ostart, rows, ovf;
+        if ((rc = rh_reserve(ctx, ocnt, ((size_t)nb + 1) * 4))) return rc;
+        if ((rc = rh_reserve(ctx, ostart, ((size_t)nb + 1) * 4))) return rc;
+        const dim3 g1((unsigned)(((uint64_t)nb + 1 + 255) / 256)), b1(256);
+        hipLaunchKernelGGL(rows_overflow_kernel, g1, b1, 0, ctx->stream, (const uint32_t *)ctx->bkt[list].p, (const uint2 *)ctx->ent[list].p,
+                           (uint64_t)nb, pbits, fbits, (uint32_t *)ocnt.p);
+        size_t tmp = 0;
+        RH_HIP(ctx, rocprim::exclusive_scan(nullptr, tmp, (uint32_t *)ocnt.p, (uint32_t *)ostart.p, 0u, (size_t)nb + 1, rocprim::plus<uint32_t>(), ctx->stream));
+        if ((rc = rh_reserve(ctx, ctx->sort_tmp, tmp ? tmp : 8))) return rc;
+        RH_HIP(ctx, rocprim::exclusive_scan(ctx->sort_tmp.p, tmp, (uint32_t *)ocnt.p, (uint32_t *)ostart.p, 0u, (size_t)nb + 1, rocprim::plus<uint32_t>(), ctx->stream));
+        uint32_t n_ovf = 0;
+        RH_HIP(ctx, hipMemcpyAsync(&n_ovf, (uint32_t *)ostart.p + nb, 4, hipMemcpyDeviceToHost, ctx->stream));
+        RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        rh_release(ocnt);
+        if ((rc = rh_reserve(ctx, rows, (size_t)nb * 128))) return rc;
+        if ((rc = rh_reserve(ctx, ovf, ((size_t)n_ovf + 1) * sizeof(uint2)))) return rc;
+        hipLaunchKernelGGL(rows_fill_kernel, dim3((unsigned)(((uint64_t)nb + 255) / 256)), b1, 0, ctx->stream, (const uint32_t *)ctx->bkt[list].p,
+                           (const uint2 *)ctx->ent[list].p, (uint64_t)nb, pbits, fbits, (const uint32_t *)ostart.p, (uint4 *)rows.p, (uint2 *)ovf.p);
+        RH_HIP(ctx, hipGetLastError());
+        RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        rh_release(ostart); rh_release(ctx->bkt[list]); rh_release(ctx->ent[list]);
+        ctx->bkt[list] = rows; ctx->ent[list] = ovf;
+        return REAL_HIP_OK;
+    }
     if (ctx->fine) {
         DevBuf fine_tab;
         if ((rc = rh_reserve(ctx, fine_tab, ((size_t)nb + 1) * sizeof(uint4)))) return rc;
@@ -539,16 +716,24 @@ int rh_index_export(real_hip_ctx *ctx, int list, void *h_sign, uint32_t *h_pos)
     int rc;
     if ((rc = rh_reserve(ctx, ctx->keys_a, n * sb))) return rc;
     if ((rc = rh_reserve(ctx, ctx->vals_a, n * 4))) return rc;
+    DevBuf unpacked; // bucket rows: the entries in list order first
+    const uint2 *d_ent = (const uint2 *)ctx->ent[list].p;
+    if (ctx->fine == 3) {
+        if ((rc = rh_reserve(ctx, unpacked, n * sizeof(uint2)))) return rc;
+        if ((rc = rh_rows_unpack(ctx, list, (uint2 *)unpacked.p, nullptr))) { rh_release(unpacked); return rc; }
+        d_ent = (const uint2 *)unpacked.p;
+    }
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
     if (sb == 4)
-        hipLaunchKernelGGL(export_kernel<uint32_t>, grid, block, 0, ctx->stream, (const uint2 *)ctx->ent[list].p,
+        hipLaunchKernelGGL(export_kernel<uint32_t>, grid, block, 0, ctx->stream, d_ent,
                            (const uint64_t *)ctx->text.p, n, l, list, (uint32_t *)ctx->keys_a.p, (uint32_t *)ctx->vals_a.p);
     else
-        hipLaunchKernelGGL(export_kernel<uint64_t>, grid, block, 0, ctx->stream, (const uint2 *)ctx->ent[list].p,
+        hipLaunchKernelGGL(export_kernel<uint64_t>, grid, block, 0, ctx->stream, d_ent,
                            (const uint64_t *)ctx->text.p, n, l, list, (uint64_t *)ctx->keys_a.p, (uint32_t *)ctx->vals_a.p);
     RH_HIP(ctx, hipGetLastError());
     if (h_sign) RH_HIP(ctx, hipMemcpyAsync(h_sign, ctx->keys_a.p, n * sb, hipMemcpyDeviceToHost, ctx->stream));
     if (h_pos) RH_HIP(ctx, hipMemcpyAsync(h_pos, ctx->vals_a.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    rh_release(unpacked);
     return REAL_HIP_OK;
 }

@@ -32,7 +32,11 @@
 // the batch.  9.5 KiB hold the 64 reads of a wave up to 151 bases each in one go; with the 8 KiB score table that
 // is 46 KiB per workgroup = three workgroups per CU, which is what the registers allow anyway.
 #define QUEUE_BYTES (MQ * 64u * 5u + 6u * 64u * 4u)
-__host__ __device__ constexpr uint32_t stg_bytes(int W) { return W <= 4 ? QUEUE_BYTES : 9728u; } // (reads up to 128 bases: as before)
+__host__ __device__ constexpr uint32_t stg_bytes(int) { return 9728u; }
+// bucket rows (table kind 3): 32 rows of 33 dwords behind the queue's positions and lists
+#define ROWBUF_OFF (MQ * 64u * 5u)
+#define ROW_STRIDE 33u
+static_assert(ROWBUF_OFF + 32u * ROW_STRIDE * 4u <= stg_bytes(0), "row staging fits the wave's LDS region");
 static_assert(stg_bytes(5) >= QUEUE_BYTES && stg_bytes(5) % 16 == 0 && QUEUE_BYTES % 16 == 0, "wave LDS region");
 #define STG_PAD 16u
 #define NPEND 2      // verified locations a lane parks until their scores are computed (flush_pending)
@@ -686,6 +690,183 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
+// ---------------------------------------------------------------------------
+// bucket rows (table kind 3): lookups by groups of eight lanes
+// ---------------------------------------------------------------------------
+// Lists [LA0, LA1) of one strand for ALL lanes of the wave (act = this lane takes part).  A lookup is one
+// 128-byte row = ONE line of HBM; it is fetched by eight lanes with one coalesced request (sixteen bytes
+// each), eight lookups per load instruction.  The wave works through its 64 lookups of a list in two halves
+// of 32: four load instructions, the rows go to LDS, then the 32 owner lanes read their row's directory and
+// -- from the same row -- the entries of their key group, apply the partner filter and queue the survivors
+// with their positions.  The loads of the next half are in flight while this one is decoded.  The queue is
+// drained by every lane for itself, in list order, when one is full and at the end.
+template <int W, bool SCORES, bool ALL, bool DEFER, int LA0, int LA1>
+__device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL, uint32_t *q_pos,
+                                                 uint8_t *q_la, uint32_t *rowbuf, bool act)
+{
+    constexpr int NL = LA1 - LA0, NS = 2 * NL;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t bb = a.b_bits;
+    const uint64_t mb = (bb >= 64) ? ~0ull : ((1ull << bb) - 1);
+    const uint64_t m[4] = {s.shi >> bb, s.shi & mb, s.slo >> bb, s.slo & mb};
+    const uint32_t gbits = a.ix.fbits, pbits = a.ix.pbits, p16 = pbits < 16 ? pbits : 16;
+    const uint32_t pmask = (1u << pbits) - 1;
+    // bucket, key group and partner bits of this lane's lookup in list LA0+i
+    uint32_t bucket[NL], grp[NL], rp[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const int la = LA0 + i;
+        const int xa = (la < 3) ? 0 : (la < 5) ? 1 : 2, xc = (la == 0) ? 1 : (la == 1 || la == 3) ? 2 : 3;
+        const uint64_t sa = (m[xa] << bb) | m[xc]; // s_a of list la, SignatureConstruction.hpp:62-67
+        bucket[i] = (uint32_t)(sa >> gbits);
+        grp[i] = (uint32_t)sa & ((1u << gbits) - 1);
+        const int lb = 5 - la; // partner signature s_b = signature of list 5-la
+        const int xb = (lb < 3) ? 0 : (lb < 5) ? 1 : 2, xd = (lb == 0) ? 1 : (lb == 1 || lb == 3) ? 2 : 3;
+        rp[i] = (uint32_t)(((m[xb] << bb) | m[xd]) >> ((a.l - pbits) & 63u));
+    }
+    uint32_t qn = 0;
+    uint4 va[4], vb[4];
+    // the four loads of step st (list st/2, owners = lanes 32*(st&1) ..+31): lane (8g+j) reads piece j of the row of owner 8*it+g
+    auto issue = [&](int st, uint4 (&v)[4]) {
+        uint32_t bk = bucket[0];
+#pragma unroll
+        for (int i = 1; i < NL; ++i) if ((st >> 1) == i) bk = bucket[i];
+        const uint4 *__restrict__ R = reinterpret_cast<const uint4 *>(a.ix.bkt[LA0 + (st >> 1)]);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int owner = 32 * (st & 1) + 8 * it + (int)(lane >> 3);
+            const uint32_t ob = __shfl(bk, owner);
+            const bool oact = __shfl((int)act, owner) != 0;
+            v[it] = oact ? R[(uint64_t)ob * 8 + (lane & 7)] : make_uint4(0, 0, 0, 0);
+        }
+    };
+    issue(0, va);
+#pragma unroll 1
+    for (int st = 0; st < NS; ++st) { // (a real loop: the drain below must exist once, not NS times)
+        if (st + 1 < NS) issue(st + 1, vb);
+        const int li = st >> 1, la = LA0 + li;
+        // rows -> LDS (row of owner slot at slot * ROW_STRIDE dwords)
+        wave_lds_sync();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            uint32_t *d = rowbuf + (8 * it + (lane >> 3)) * ROW_STRIDE + (lane & 7) * 4;
+            d[0] = va[it].x; d[1] = va[it].y; d[2] = va[it].z; d[3] = va[it].w;
+        }
+        wave_lds_sync();
+        // owners: directory of the row, then the entries of their key group
+        const bool mine = act && (int)(lane >> 5) == (st & 1) && !(DEFER && s.p_n == PEND_OVF);
+        const uint32_t *row = rowbuf + (lane & 31) * ROW_STRIDE;
+        uint32_t e_cnt = 0, e_j = 0, e_base = 0;
+        bool e_ovf = false;
+        uint32_t g = grp[0], r = rp[0];
+#pragma unroll
+        for (int i = 1; i < NL; ++i) if (li == i) { g = grp[i]; r = rp[i]; }
+        if (mine) {
+            s.cL++;
+            const uint64_t hdr = (uint64_t)row[0] | ((uint64_t)row[1] << 32);
+            if (hdr != ~0ull) {
+                e_cnt = (uint32_t)(hdr >> (4 * g)) & 15u;
+                uint64_t x = g ? (hdr & (~0ull >> (64 - 4 * g))) : 0ull; // the nibbles in front of mine, summed
+                x = (x & 0x0f0f0f0f0f0f0f0full) + ((x >> 4) & 0x0f0f0f0f0f0f0f0full);
+                e_base = (uint32_t)((x * 0x0101010101010101ull) >> 56);
+            } else { // complex bucket: its entries are in the overflow array; 8-bit group counts
+                e_ovf = true;
+                uint32_t off = 0;
+                bool sat = false;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const uint32_t c8 = (row[4 + (q >> 2)] >> (8 * (q & 3))) & 255u;
+                    if ((uint32_t)q < g) { off += c8; sat = sat || c8 == 255u; }
+                    if ((uint32_t)q == g) { e_cnt = c8; sat = sat || c8 == 255u; }
+                }
+                e_base = row[2] + off;
+                if (sat) { // a group of 255 or more entries in front of / at the key: bounds by binary search
+                    const uint2 *__restrict__ E = a.ix.ent[la];
+                    uint32_t x = row[2], y = row[2] + row[3];
+                    const uint32_t end = y;
+                    while (x < y) { uint32_t mid = x + ((y - x) >> 1); if ((E[mid].x >> pbits) < g) x = mid + 1; else y = mid; }
+                    e_base = x; y = end;
+                    while (x < y) { uint32_t mid = x + ((y - x) >> 1); if ((E[mid].x >> pbits) <= g) x = mid + 1; else y = mid; }
+                    e_cnt = x - e_base;
+                }
+            }
+            s.cC += e_cnt; s.cP += e_cnt;
+        }
+        while (true) {
+            while (e_j < e_cnt && qn < MQ) {
+                uint32_t key, pos;
+                bool pass;
+                if (!e_ovf) { // 6 bytes at halfword 4 + 3 * (e_base + e_j) of the row
+                    const uint32_t h = 4 + 3 * (e_base + e_j);
+                    const uint32_t d0 = row[h >> 1], d1 = row[(h >> 1) + 1];
+                    key = (h & 1) ? (d0 >> 16) : (d0 & 0xffffu);
+                    pos = (h & 1) ? d1 : ((d0 >> 16) | (d1 << 16));
+                    const uint32_t x = key ^ (r >> (pbits - p16));
+                    pass = __popc(((x >> 1) | x) & 0x5555u) <= a.seedkmax;
+                } else {
+                    const uint2 e = a.ix.ent[la][e_base + e_j];
+                    pos = e.y;
+                    const uint32_t x = (e.x & pmask) ^ r;
+                    pass = __popc(((x >> 1) | x) & 0x55555555u) <= a.seedkmax;
+                }
+                // seed popcount filter (match.hpp:386) on the partner symbols the entry carries: more than seedkmax
+                // known mismatches => rejected without touching the text (exact: the full count can only be larger)
+                if (pass) { q_pos[qn * 64] = pos; q_la[qn * 64] = (uint8_t)la; qn++; }
+                e_j++;
+            }
+            const bool more = e_j < e_cnt;
+            if (!__any(more) && st + 1 < NS) break;
+            // a full queue somewhere, or the end of the lists: verify / score / fold in candidate order
+            for (uint32_t k = 0; k < qn; ++k)
+                process_candidate<W, SCORES, ALL, DEFER>(a, s, sLL, q_pos[k * 64], (int)q_la[k * 64]);
+            qn = 0;
+            if (DEFER && s.p_n == PEND_OVF) e_j = e_cnt;
+            if (!__any(e_j < e_cnt)) break;
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) va[it] = vb[it];
+    }
+}
+
+// both strands of one read with bucket rows: every lane of the wave comes along, `act` tells which ones have a read
+template <int W, bool SCORES, bool ALL, bool DEFER>
+__device__ __forceinline__ void match_read_rows(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL, uint32_t *q_pos,
+                                                uint8_t *q_la, uint32_t *rowbuf, bool act)
+{
+    const uint32_t patl = act ? s.patl : 32u * W;
+    s.nw = (patl + 31) >> 5;
+    s.lastmask = ~0ull << (64 - 2 * (patl - 32 * (s.nw - 1)));
+    s.eps = (float)(a.filter_mult * (double)patl); // RealOptions.hpp:74-77
+    s.p_n = s.p_nev = s.p_ev = 0; s.cslot = SLOT_NONE;
+    uint64_t rhi = 0, rlo = 0;
+    if (act) seed_halves<W>(s.O, a.l, s.shi, s.slo, rhi, rlo);
+    else { s.shi = s.slo = 0; }
+    for (int inv = 0; inv < 2; ++inv) {
+        if (inv && act) { // transposed pattern, Pattern.hpp:105-128
+            uint64_t R[W];
+            revcomp_words<W>(s.O, R, patl);
+#pragma unroll
+            for (int j = 0; j < W; ++j) s.O[j] = R[j];
+            s.shi = rhi; s.slo = rlo;
+        }
+        s.inv = inv;
+        s.so = inv ? (patl - a.l) : 0u; // RestMatch::getMatchOffset, RestMatch.hpp:84-89
+        s.cpos = 0xffffffffu; s.ck = 0; s.cfrag = 0; s.cscore = 1.0f; s.cok = false;
+        s.crpos = 0xffffffffu; s.ckk = 0;
+        const bool go = act && !(DEFER && s.p_n == PEND_OVF);
+        if (!ALL && !SCORES) {
+            // uni0s / uni0r early-out (matchUniqueImplementation.cpp:434-436, 470-472): lists 1..5 of a
+            // strand are skipped when list 0 left the record in this strand's state with 0 errors
+            match_lists_rows<W, SCORES, ALL, DEFER, 0, 1>(a, s, sLL, q_pos, q_la, rowbuf, go);
+            const unsigned st = (unsigned)(s.info >> ST_SHIFT), er = (unsigned)(s.info >> ER_SHIFT) & 15;
+            match_lists_rows<W, SCORES, ALL, DEFER, 1, 6>(a, s, sLL, q_pos, q_la, rowbuf,
+                                                          go && !(st == (unsigned)(inv ? ST_REVERSE : ST_STRAIGHT) && er == 0));
+        } else {
+            match_lists_rows<W, SCORES, ALL, DEFER, 0, 6>(a, s, sLL, q_pos, q_la, rowbuf, go);
+        }
+    }
+}
+
 // both strands of one read (UniqueMatcher::match / AllMatcher::match, matchUniqueImplementation.cpp:396-500,
 // matchAllImplementation.cpp:261-355): s.O holds the read as given on entry, its reverse complement on exit
 template <int W, bool SCORES, bool ALL, bool FINE, bool DEFER>
@@ -773,13 +954,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
         wave_lds_sync();
         // ---- match
         s.r = r; s.patl = patl; s.p_n = 0; s.nhit = 0;
-        if (elig) {
-            if (!ALL) {
-                s.info = a.info[r];
-                if (SCORES) s.iscore = a.score[r];
-            }
-            match_read<W, SCORES, ALL, FINE, DEFER>(a, s, sLL, q_pos, q_la, q_cur);
+        if (elig && !ALL) {
+            s.info = a.info[r];
+            if (SCORES) s.iscore = a.score[r];
         }
+        if (FINE && a.ix.fine == 3) // bucket rows: lookups by lane groups, the whole wave comes along
+            match_read_rows<W, SCORES, ALL, DEFER>(a, s, sLL, q_pos, q_la, reinterpret_cast<uint32_t *>(stg + ROWBUF_OFF), elig);
+        else if (elig)
+            match_read<W, SCORES, ALL, FINE, DEFER>(a, s, sLL, q_pos, q_la, q_cur);
         const bool ovf = DEFER && elig && s.p_n == PEND_OVF;
         if (ovf) {
             // nothing of this read has been delivered: the repeat kernel does it all and counts it
@@ -810,17 +992,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
         if (ALL && r < n) a.hit_cnt[r] = (elig && !ovf) ? s.nhit : 0u; // (a handed-over read: the repeat kernel writes it)
     } else {
         const uint64_t n_items = (uint64_t)*a.ovf_count;
-        for (uint64_t it = (uint64_t)blockIdx.x * 256 + threadIdx.x; it < n_items; it += (uint64_t)gridDim.x * 256) {
-            const uint64_t r = a.ovf_list[it];
+        // (every lane of a wave makes the same number of trips: the row lookups are wave-wide)
+        for (uint64_t it0 = (uint64_t)blockIdx.x * 256; it0 < n_items; it0 += (uint64_t)gridDim.x * 256) {
+            const uint64_t it = it0 + threadIdx.x;
+            const bool have = it < n_items;
+            const uint64_t r = have ? a.ovf_list[it] : 0;
             const uint64_t o0 = a.b.off ? a.b.off[r] : r * (uint64_t)a.b.upatl;
             const uint32_t patl = a.b.off ? (uint32_t)(a.b.off[r + 1] - o0) : a.b.upatl;
             s.r = r; s.o0 = o0; s.patl = patl; s.nhit = 0;
-            pack_read<W>(GlobalRow{a.b.bases + o0}, patl, s.O); // (eligible: the matcher handed it over)
-            if (!ALL) {
-                s.info = a.info[r];
-                if (SCORES) s.iscore = a.score[r];
+            if (have) {
+                pack_read<W>(GlobalRow{a.b.bases + o0}, patl, s.O); // (eligible: the matcher handed it over)
+                if (!ALL) {
+                    s.info = a.info[r];
+                    if (SCORES) s.iscore = a.score[r];
+                }
             }
-            match_read<W, SCORES, ALL, FINE, DEFER>(a, s, sLL, q_pos, q_la, q_cur);
+            if (FINE && a.ix.fine == 3)
+                match_read_rows<W, SCORES, ALL, DEFER>(a, s, sLL, q_pos, q_la, reinterpret_cast<uint32_t *>(stg + ROWBUF_OFF), have);
+            else if (have)
+                match_read<W, SCORES, ALL, FINE, DEFER>(a, s, sLL, q_pos, q_la, q_cur);
+            if (!have) continue;
             cR++;
             if (!ALL) {
                 a.info[r] = s.info;

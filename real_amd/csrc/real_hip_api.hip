@@ -349,10 +349,24 @@ extern "C" int real_hip_index_download(real_hip_ctx *ctx, int list, uint32_t *en
     if (!ctx->have_index) return rh_fail(ctx, REAL_HIP_E_STATE, "no index", hipSuccess);
     if (list < 0 || list > 5) return rh_fail(ctx, REAL_HIP_E_INVALID, "list", hipSuccess);
     const uint64_t n = ctx->n_entries;
+    if (ctx->fine == 3) { // bucket rows: entries and bucket starts by an ordered traversal of the rows
+        DevBuf e, st;
+        int rc;
+        if ((rc = rh_reserve(ctx, e, (n ? n : 1) * sizeof(uint2)))) return rc;
+        if ((rc = rh_reserve(ctx, st, (((size_t)1 << ctx->pb) + 1) * 4))) { rh_release(e); return rc; }
+        rc = rh_rows_unpack(ctx, list, (uint2 *)e.p, (uint32_t *)st.p);
+        hipError_t he = hipSuccess;
+        if (!rc && n && entries) he = hipMemcpy(entries, e.p, n * sizeof(uint2), hipMemcpyDeviceToHost);
+        if (!rc && he == hipSuccess && bucket) he = hipMemcpy(bucket, st.p, (((size_t)1 << ctx->pb) + 1) * 4, hipMemcpyDeviceToHost);
+        rh_release(e); rh_release(st);
+        if (rc) return rc;
+        if (he != hipSuccess) return rh_fail(ctx, REAL_HIP_E_DEVICE, "index download", he);
+        return REAL_HIP_OK;
+    }
     if (n && entries) RH_HIP(ctx, hipMemcpy(entries, ctx->ent[list].p, n * sizeof(uint2), hipMemcpyDeviceToHost));
     if (bucket) {
         const size_t nbk = ((size_t)1 << ctx->pb) + 1;
-        if (ctx->fine) RH_HIP(ctx, hipMemcpy2D(bucket, 4, ctx->bkt[list].p, 16, 4, nbk, hipMemcpyDeviceToHost)); // the .x of every uint4
+        if (ctx->fine) RH_HIP(ctx, hipMemcpy2D(bucket, 4, ctx->bkt[list].p, 16, 4, nbk, hipMemcpyDeviceToHost)); // the .x of every uint4 (kinds 1, 2)
         else RH_HIP(ctx, hipMemcpy(bucket, ctx->bkt[list].p, nbk * 4, hipMemcpyDeviceToHost));
     }
     return REAL_HIP_OK;

@@ -41,7 +41,8 @@ struct DevIndex {
     uint32_t fbits;  // signature bits kept in the entry (all sig_bits - pb of them when that is <= 30)
     uint32_t pbits;  // partner-signature bits kept in the entry (even; 0 when the signature needs all 32)
     uint32_t fine;   // bucket table kind: 0 u32 starts; 1 "fine": size + partner digest of every key group of the bucket
-                     // (fbits <= 3); 2 fingerprints of the bucket's first entries (pbits == 0, wide signatures)
+                     // (fbits <= 3); 2 fingerprints of the bucket's first entries (pbits == 0, wide signatures);
+                     // 3 bucket rows: bkt[] holds one 128-byte row per bucket (directory + entries), ent[] the overflow
 };
 
 // "fine" bucket tables: the prefix is all signature bits but one to three, so a bucket has at most eight key
@@ -50,6 +51,7 @@ static inline bool rh_is_fine(uint32_t l, uint32_t pb) { return l >= pb && l - p
 #define RH_FINE_SAT 15u /* group size field: 15 = "15 or more", bounds by binary search */
 // fingerprint tables: uint4 {start, count:8 | 8 x fingerprint:11}: the first eight entries of the bucket by an
 // 11-bit hash of their 32-bit key; a lookup whose own fingerprint is not among them reads no entry at all
+#define RH_ROW_CAP 20u /* entries a bucket row holds (table kind 3) */
 #define RH_FP_SLOTS 8u
 static inline __host__ __device__ uint32_t rh_fp11(uint32_t key) { return (key * 0x9E3779B1u) >> 21; }
 
@@ -182,3 +184,4 @@ int rh_index_from_sorted(real_hip_ctx *ctx, int list, const void *d_sign, const 
 int rh_index_build_device(real_hip_ctx *ctx, uint64_t first_window, uint64_t max_entries,
                           uint64_t *n_entries, int *have_next);
 void rh_choose_tables(real_hip_ctx *ctx, uint64_t n_entries); // sets ctx->pb and ctx->fine
+int rh_rows_unpack(real_hip_ctx *ctx, int list, uint2 *d_entries, uint32_t *d_starts);

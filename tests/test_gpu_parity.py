@@ -131,6 +131,8 @@ def test_match_all_golden_inputs(ora, path):
     (32, 100, 3, 1, 29),
     # fingerprint bucket tables (64-bit signatures): mean bucket 6 (some overflow eight slots), 0.4 and 50 entries
     (64, 150, 5, 1, -15), (64, 150, 5, 0, -19), (48, 100, 4, 1, -12), (36, 80, 3, 1, -4),
+    # bucket rows (pb + 100): 8 / 16 signature values per row, rows of 6..100 entries (most of them complex at pb 12 / 5)
+    (16, 50, 4, 1, 113), (16, 50, 4, 0, 112), (16, 50, 4, 1, 115), (12, 40, 4, 1, 109), (8, 30, 3, 1, 105), (20, 255, 15, 1, 116),
 ])
 def test_match_unique_random(ora, seedl, patl, k, scores, pb):
     # (short seeds on a 3 kbp genome: equal ranges of hundreds of entries -> queue refills, saturated groups)
@@ -139,7 +141,7 @@ def test_match_unique_random(ora, seedl, patl, k, scores, pb):
     seedk = min(2, k)
     p = ora.make_params(seedl=seedl, seedkmax=seedk, totalkmax=k, scores=scores)
     oinfo, oscore, octr = _oracle_unique(ora, None, g.sym, g.frag_start, seedl, 0, p, b.bases, b.qual, b.offsets)
-    m = UniqueMatcher(_opts(seedl, seedk, k, scores), prefix_bits=abs(pb), table_kind=2 if pb < 0 else 0)   # pb < 0: directory tables forced
+    m = UniqueMatcher(_opts(seedl, seedk, k, scores), prefix_bits=abs(pb) % 100, table_kind=3 if pb >= 100 else (2 if pb < 0 else 0))   # pb < 0: directory tables, pb >= 100: bucket rows
     m.set_text_symbols(0, g.sym, g.frag_start)
     m.build_index_block()
     info, score = m.match_unique(b.bases, b.qual, patl=patl)        # uniform-length batch form
@@ -170,8 +172,8 @@ def test_match_all_fine_tables(ora):
     m.close()
 
 
-@pytest.mark.parametrize("scores", [1, 0])
-def test_match_all_many_hits_per_read(ora, scores):
+@pytest.mark.parametrize("scores,rows", [(1, 0), (0, 0), (1, 1)])
+def test_match_all_many_hits_per_read(ora, scores, rows):
     # 8-base seeds on a 3 kbp tandem repeat (period 40, 2 % diverged copies): tens of hits per read -- the per-read
     # ordering pass takes its workgroup-per-read path (> 32 hits), the matcher its repeat pass (scores on)
     g = synth.random_genome(3000, seed=31, n_frag=2)
@@ -184,7 +186,7 @@ def test_match_all_many_hits_per_read(ora, scores):
     p = ora.make_params(seedl=8, seedkmax=2, totalkmax=4, scores=scores)
     ohits, ooff, octr = ora.match_all(og, ix, p, b.bases, b.qual, b.offsets)
     assert int(np.diff(ooff).max()) > 32, "test data must hold a read with more than 32 hits"
-    m = AllMatcher(_opts(8, 2, 4, scores))
+    m = AllMatcher(_opts(8, 2, 4, scores), prefix_bits=5 if rows else 0, table_kind=3 if rows else 0)
     m.set_text_symbols(0, g.sym, g.frag_start)
     m.build_index_block()
     hits, hoff = m.match_all(b.bases, b.qual, b.offsets, cap=len(ohits) + 8)   # (no overflow retry: work counted once)
@@ -199,11 +201,11 @@ def test_match_all_many_hits_per_read(ora, scores):
 
 def test_index_layout_device_equals_host(ora):
     g = synth.random_genome(50_000, seed=77, n_frag=3, n_runs=10, repeats=10)
-    for seedl in (32, 64, 12):
-        a = UniqueMatcher(_opts(seedl, 2, 3, 1))
+    for seedl, kw in ((32, {}), (64, {}), (12, {}), (16, dict(table_kind=3, prefix_bits=12)), (16, dict(table_kind=3))):
+        a = UniqueMatcher(_opts(seedl, 2, 3, 1), **kw)
         a.set_text_symbols(0, g.sym, g.frag_start)
         a.build_index_block()
-        h = UniqueMatcher(_opts(seedl, 2, 3, 1))
+        h = UniqueMatcher(_opts(seedl, 2, 3, 1), **kw)
         text, wild = host_index.pack_text(g.sym)
         h.set_text(0, text, wild, g.n, g.frag_start)
         sign, pos, n, nxt = host_index.build_lists(g.sym, seedl)
