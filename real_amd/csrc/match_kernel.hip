@@ -32,12 +32,11 @@
 // the batch.  9.5 KiB hold the 64 reads of a wave up to 151 bases each in one go; with the 8 KiB score table that
 // is 46 KiB per workgroup = three workgroups per CU, which is what the registers allow anyway.
 #define QUEUE_BYTES (MQ * 64u * 5u + 6u * 64u * 4u)
-__host__ __device__ constexpr uint32_t stg_bytes(int) { return 9728u; }
-// bucket rows (table kind 3): 32 rows of 33 dwords behind the queue's positions and lists
-#define ROWBUF_OFF (MQ * 64u * 5u)
-#define ROW_STRIDE 33u
-static_assert(ROWBUF_OFF + 32u * ROW_STRIDE * 4u <= stg_bytes(0), "row staging fits the wave's LDS region");
-static_assert(stg_bytes(5) >= QUEUE_BYTES && stg_bytes(5) % 16 == 0 && QUEUE_BYTES % 16 == 0, "wave LDS region");
+__host__ __device__ constexpr uint32_t stg_bytes(int W, int TK) { return TK == 3 ? 10752u : (W <= 4 ? QUEUE_BYTES : 9728u); }
+// bucket rows (table kind 3): a queue of MQR slots per lane, then the 64 rows of a list, 128 bytes each
+#define MQR 8u
+#define ROWBUF_OFF (MQR * 64u * 5u)
+static_assert(ROWBUF_OFF + 64u * 128u <= stg_bytes(4, 3) && ROWBUF_OFF % 16 == 0 && QUEUE_BYTES % 16 == 0, "row staging fits the wave's LDS region");
 #define STG_PAD 16u
 #define NPEND 2      // verified locations a lane parks until their scores are computed (flush_pending)
 #define PEND_EV 32   // update() events parked with them
@@ -701,88 +700,95 @@ __device__ __forceinline__ void wave_lds_sync()
 // with their positions.  The loads of the next half are in flight while this one is decoded.  The queue is
 // drained by every lane for itself, in list order, when one is full and at the end.
 template <int W, bool SCORES, bool ALL, bool DEFER, int LA0, int LA1>
-__device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL, uint32_t *q_pos,
-                                                 uint8_t *q_la, uint32_t *rowbuf, bool act)
+__device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL, uint8_t *stg, bool act)
 {
-    constexpr int NL = LA1 - LA0, NS = 2 * NL;
+    constexpr int NL = LA1 - LA0;
     const uint32_t lane = threadIdx.x & 63;
+    // the wave's LDS region in this mode: MQR x 64 queued positions, MQR x 64 lists, 64 rows of 128 bytes
+    uint32_t *q_pos = reinterpret_cast<uint32_t *>(stg) + lane;
+    uint8_t *q_la = stg + MQR * 64 * 4 + lane;
+    uint8_t *rowbuf = stg + ROWBUF_OFF;
     const uint32_t bb = a.b_bits;
-    const uint64_t mb = (bb >= 64) ? ~0ull : ((1ull << bb) - 1);
-    const uint64_t m[4] = {s.shi >> bb, s.shi & mb, s.slo >> bb, s.slo & mb};
     const uint32_t gbits = a.ix.fbits, pbits = a.ix.pbits, p16 = pbits < 16 ? pbits : 16;
     const uint32_t pmask = (1u << pbits) - 1;
-    // bucket, key group and partner bits of this lane's lookup in list LA0+i
-    uint32_t bucket[NL], grp[NL], rp[NL];
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-        const int la = LA0 + i;
-        const int xa = (la < 3) ? 0 : (la < 5) ? 1 : 2, xc = (la == 0) ? 1 : (la == 1 || la == 3) ? 2 : 3;
-        const uint64_t sa = (m[xa] << bb) | m[xc]; // s_a of list la, SignatureConstruction.hpp:62-67
-        bucket[i] = (uint32_t)(sa >> gbits);
-        grp[i] = (uint32_t)sa & ((1u << gbits) - 1);
-        const int lb = 5 - la; // partner signature s_b = signature of list 5-la
-        const int xb = (lb < 3) ? 0 : (lb < 5) ? 1 : 2, xd = (lb == 0) ? 1 : (lb == 1 || lb == 3) ? 2 : 3;
-        rp[i] = (uint32_t)(((m[xb] << bb) | m[xd]) >> ((a.l - pbits) & 63u));
+    // the six signatures of the strand (32 bits: seedl <= 32); the partner of list k is list 5-k
+    uint32_t sig[6];
+    {
+        const uint32_t mb = (1u << bb) - 1;
+        const uint32_t m0 = (uint32_t)(s.shi >> bb), m1 = (uint32_t)s.shi & mb, m2 = (uint32_t)(s.slo >> bb), m3 = (uint32_t)s.slo & mb;
+        sig[0] = (m0 << bb) | m1; sig[1] = (m0 << bb) | m2; sig[2] = (m0 << bb) | m3; // SignatureConstruction.hpp:62-67
+        sig[3] = (m1 << bb) | m2; sig[4] = (m1 << bb) | m3; sig[5] = (m2 << bb) | m3;
     }
+    auto sig_of = [&](int la) {
+        uint32_t v = sig[0];
+#pragma unroll
+        for (int i = 1; i < 6; ++i) if (la == i) v = sig[i];
+        return v;
+    };
     uint32_t qn = 0;
-    uint4 va[4], vb[4];
-    // the four loads of step st (list st/2, owners = lanes 32*(st&1) ..+31): lane (8g+j) reads piece j of the row of owner 8*it+g
-    auto issue = [&](int st, uint4 (&v)[4]) {
-        uint32_t bk = bucket[0];
+    uint4 va[8], vb[8];
+    // the eight loads of list la: lane (8g+j) reads piece j of the row of owner 8*it+g (bucket ~0 = owner takes no part)
+    auto issue = [&](int la, uint4 (&v)[8]) {
+        const uint32_t bk = act ? (sig_of(la) >> gbits) : 0xffffffffu;
+        const uint4 *__restrict__ R = reinterpret_cast<const uint4 *>(a.ix.bkt[la]);
 #pragma unroll
-        for (int i = 1; i < NL; ++i) if ((st >> 1) == i) bk = bucket[i];
-        const uint4 *__restrict__ R = reinterpret_cast<const uint4 *>(a.ix.bkt[LA0 + (st >> 1)]);
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int owner = 32 * (st & 1) + 8 * it + (int)(lane >> 3);
-            const uint32_t ob = __shfl(bk, owner);
-            const bool oact = __shfl((int)act, owner) != 0;
-            v[it] = oact ? R[(uint64_t)ob * 8 + (lane & 7)] : make_uint4(0, 0, 0, 0);
+        for (int it = 0; it < 8; ++it) {
+            const uint32_t ob = __shfl(bk, 8 * it + (int)(lane >> 3));
+            v[it] = (ob != 0xffffffffu) ? R[(uint64_t)ob * 8 + (lane & 7)] : make_uint4(0, 0, 0, 0);
         }
     };
-    issue(0, va);
+    issue(LA0, va);
 #pragma unroll 1
-    for (int st = 0; st < NS; ++st) { // (a real loop: the drain below must exist once, not NS times)
-        if (st + 1 < NS) issue(st + 1, vb);
-        const int li = st >> 1, la = LA0 + li;
-        // rows -> LDS (row of owner slot at slot * ROW_STRIDE dwords)
+    for (int li = 0; li < NL; ++li) { // (a real loop: the drain below must exist once, not NL times)
+        const int la = LA0 + li;
+        if (li + 1 < NL) issue(la + 1, vb);
+        // rows -> LDS: piece j of row r at r * 128 + ((j ^ (r & 7)) * 16) (16-byte stores; the swizzle spreads the owners'
+        // reads of the same dword of different rows over eight bank groups)
         wave_lds_sync();
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            uint32_t *d = rowbuf + (8 * it + (lane >> 3)) * ROW_STRIDE + (lane & 7) * 4;
-            d[0] = va[it].x; d[1] = va[it].y; d[2] = va[it].z; d[3] = va[it].w;
+        for (int it = 0; it < 8; ++it) {
+            const uint32_t r = 8 * it + (lane >> 3), j = lane & 7;
+            *reinterpret_cast<uint4 *>(rowbuf + r * 128 + ((j ^ (r & 7)) * 16)) = va[it];
         }
         wave_lds_sync();
         // owners: directory of the row, then the entries of their key group
-        const bool mine = act && (int)(lane >> 5) == (st & 1) && !(DEFER && s.p_n == PEND_OVF);
-        const uint32_t *row = rowbuf + (lane & 31) * ROW_STRIDE;
+        const bool mine = act && !(DEFER && s.p_n == PEND_OVF);
+        const uint8_t *rowb = rowbuf + lane * 128;
+        const uint32_t sw = lane & 7;
+        auto row = [&](uint32_t d) { return *reinterpret_cast<const uint32_t *>(rowb + ((((d >> 2) ^ sw) << 4) | ((d & 3) << 2))); };
         uint32_t e_cnt = 0, e_j = 0, e_base = 0;
         bool e_ovf = false;
-        uint32_t g = grp[0], r = rp[0];
-#pragma unroll
-        for (int i = 1; i < NL; ++i) if (li == i) { g = grp[i]; r = rp[i]; }
+        const uint32_t sa = sig_of(la), g = sa & ((1u << gbits) - 1);
+        const uint32_t r = sig_of(5 - la) >> (a.l - pbits); // partner bits of the read: leading pbits of s_b
         if (mine) {
             s.cL++;
-            const uint64_t hdr = (uint64_t)row[0] | ((uint64_t)row[1] << 32);
-            if (hdr != ~0ull) {
-                e_cnt = (uint32_t)(hdr >> (4 * g)) & 15u;
-                uint64_t x = g ? (hdr & (~0ull >> (64 - 4 * g))) : 0ull; // the nibbles in front of mine, summed
-                x = (x & 0x0f0f0f0f0f0f0f0full) + ((x >> 4) & 0x0f0f0f0f0f0f0f0full);
-                e_base = (uint32_t)((x * 0x0101010101010101ull) >> 56);
+            const uint32_t h0 = row(0), h1 = row(1);
+            if ((h0 & h1) != 0xffffffffu) {
+                // sixteen 4-bit counts: mine, and the sum of those in front of it
+                e_cnt = ((g < 8 ? h0 : h1) >> (4 * (g & 7))) & 15u;
+                const uint32_t m0 = g < 8 ? (g ? (h0 & (0xffffffffu >> (32 - 4 * g))) : 0u) : h0;
+                const uint32_t m1 = g > 8 ? (h1 & (0xffffffffu >> (32 - 4 * (g - 8)))) : 0u;
+                const uint32_t b0 = (m0 & 0x0f0f0f0fu) + ((m0 >> 4) & 0x0f0f0f0fu), b1 = (m1 & 0x0f0f0f0fu) + ((m1 >> 4) & 0x0f0f0f0fu);
+                e_base = __builtin_amdgcn_sad_u8(b0, 0u, __builtin_amdgcn_sad_u8(b1, 0u, 0u));
             } else { // complex bucket: its entries are in the overflow array; 8-bit group counts
                 e_ovf = true;
                 uint32_t off = 0;
                 bool sat = false;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const uint32_t c8 = (row[4 + (q >> 2)] >> (8 * (q & 3))) & 255u;
-                    if ((uint32_t)q < g) { off += c8; sat = sat || c8 == 255u; }
-                    if ((uint32_t)q == g) { e_cnt = c8; sat = sat || c8 == 255u; }
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t w = row(4 + q);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const uint32_t c8 = (w >> (8 * t)) & 255u, gi = 4 * q + t;
+                        if (gi < g) { off += c8; sat = sat || c8 == 255u; }
+                        if (gi == g) { e_cnt = c8; sat = sat || c8 == 255u; }
+                    }
                 }
-                e_base = row[2] + off;
+                const uint32_t o0 = row(2), tot = row(3);
+                e_base = o0 + off;
                 if (sat) { // a group of 255 or more entries in front of / at the key: bounds by binary search
                     const uint2 *__restrict__ E = a.ix.ent[la];
-                    uint32_t x = row[2], y = row[2] + row[3];
+                    uint32_t x = o0, y = o0 + tot;
                     const uint32_t end = y;
                     while (x < y) { uint32_t mid = x + ((y - x) >> 1); if ((E[mid].x >> pbits) < g) x = mid + 1; else y = mid; }
                     e_base = x; y = end;
@@ -793,13 +799,13 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
             s.cC += e_cnt; s.cP += e_cnt;
         }
         while (true) {
-            while (e_j < e_cnt && qn < MQ) {
-                uint32_t key, pos;
+            while (e_j < e_cnt && qn < MQR) {
+                uint32_t pos;
                 bool pass;
                 if (!e_ovf) { // 6 bytes at halfword 4 + 3 * (e_base + e_j) of the row
                     const uint32_t h = 4 + 3 * (e_base + e_j);
-                    const uint32_t d0 = row[h >> 1], d1 = row[(h >> 1) + 1];
-                    key = (h & 1) ? (d0 >> 16) : (d0 & 0xffffu);
+                    const uint32_t d0 = row(h >> 1), d1 = row((h >> 1) + 1);
+                    const uint32_t key = (h & 1) ? (d0 >> 16) : (d0 & 0xffffu);
                     pos = (h & 1) ? d1 : ((d0 >> 16) | (d1 << 16));
                     const uint32_t x = key ^ (r >> (pbits - p16));
                     pass = __popc(((x >> 1) | x) & 0x5555u) <= a.seedkmax;
@@ -814,8 +820,7 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
                 if (pass) { q_pos[qn * 64] = pos; q_la[qn * 64] = (uint8_t)la; qn++; }
                 e_j++;
             }
-            const bool more = e_j < e_cnt;
-            if (!__any(more) && st + 1 < NS) break;
+            if (!__any(e_j < e_cnt) && li + 1 < NL) break;
             // a full queue somewhere, or the end of the lists: verify / score / fold in candidate order
             for (uint32_t k = 0; k < qn; ++k)
                 process_candidate<W, SCORES, ALL, DEFER>(a, s, sLL, q_pos[k * 64], (int)q_la[k * 64]);
@@ -824,14 +829,13 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
             if (!__any(e_j < e_cnt)) break;
         }
 #pragma unroll
-        for (int it = 0; it < 4; ++it) va[it] = vb[it];
+        for (int it = 0; it < 8; ++it) va[it] = vb[it];
     }
 }
 
 // both strands of one read with bucket rows: every lane of the wave comes along, `act` tells which ones have a read
 template <int W, bool SCORES, bool ALL, bool DEFER>
-__device__ __forceinline__ void match_read_rows(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL, uint32_t *q_pos,
-                                                uint8_t *q_la, uint32_t *rowbuf, bool act)
+__device__ __forceinline__ void match_read_rows(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL, uint8_t *stg, bool act)
 {
     const uint32_t patl = act ? s.patl : 32u * W;
     s.nw = (patl + 31) >> 5;
@@ -857,12 +861,11 @@ __device__ __forceinline__ void match_read_rows(const MatchArgs &a, LaneState<W,
         if (!ALL && !SCORES) {
             // uni0s / uni0r early-out (matchUniqueImplementation.cpp:434-436, 470-472): lists 1..5 of a
             // strand are skipped when list 0 left the record in this strand's state with 0 errors
-            match_lists_rows<W, SCORES, ALL, DEFER, 0, 1>(a, s, sLL, q_pos, q_la, rowbuf, go);
+            match_lists_rows<W, SCORES, ALL, DEFER, 0, 1>(a, s, sLL, stg, go);
             const unsigned st = (unsigned)(s.info >> ST_SHIFT), er = (unsigned)(s.info >> ER_SHIFT) & 15;
-            match_lists_rows<W, SCORES, ALL, DEFER, 1, 6>(a, s, sLL, q_pos, q_la, rowbuf,
-                                                          go && !(st == (unsigned)(inv ? ST_REVERSE : ST_STRAIGHT) && er == 0));
+            match_lists_rows<W, SCORES, ALL, DEFER, 1, 6>(a, s, sLL, stg, go && !(st == (unsigned)(inv ? ST_REVERSE : ST_STRAIGHT) && er == 0));
         } else {
-            match_lists_rows<W, SCORES, ALL, DEFER, 0, 6>(a, s, sLL, q_pos, q_la, rowbuf, go);
+            match_lists_rows<W, SCORES, ALL, DEFER, 0, 6>(a, s, sLL, stg, go);
         }
     }
 }
@@ -913,18 +916,20 @@ __device__ __forceinline__ void match_read(const MatchArgs &a, LaneState<W, SCOR
 // than NPEND locations / PEND_EV events is left untouched and its index appended to a.ovf_list.
 // REPEAT = true: the same matcher with in-place scoring over the reads of a.ovf_list (grid-stride; the list
 // length is read from device memory, no host round trip); a lane fetches the bytes of its read itself.
-template <int W, bool SCORES, bool ALL, bool FINE, bool REPEAT>
+// TK = kind of the bucket tables: 0 bucket starts, 1 directory entries (digests / fingerprints), 3 bucket rows
+template <int W, bool SCORES, bool ALL, int TK, bool REPEAT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 : 2))) void match_kernel(MatchArgs a)
 {
+    constexpr bool FINE = TK != 0;
     constexpr bool DEFER = SCORES && !REPEAT;
     __shared__ double sLL[SCORES ? 1024 : 1];
-    __shared__ __attribute__((aligned(16))) uint8_t smem[4 * stg_bytes(W)];
+    __shared__ __attribute__((aligned(16))) uint8_t smem[4 * stg_bytes(W, TK)];
     if (SCORES) {
         for (int i = threadIdx.x; i < 1024; i += 256) sLL[i] = a.LL[i];
         __syncthreads();
     }
     const uint32_t lane = threadIdx.x & 63;
-    uint8_t *stg = smem + (threadIdx.x >> 6) * stg_bytes(W);
+    uint8_t *stg = smem + (threadIdx.x >> 6) * stg_bytes(W, TK);
     uint32_t *q_pos = reinterpret_cast<uint32_t *>(stg) + lane;
     uint8_t *q_la = stg + MQ * 64 * 4 + lane;
     uint32_t *q_cur = reinterpret_cast<uint32_t *>(stg + MQ * 64 * 5) + lane;
@@ -958,8 +963,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
             s.info = a.info[r];
             if (SCORES) s.iscore = a.score[r];
         }
-        if (FINE && a.ix.fine == 3) // bucket rows: lookups by lane groups, the whole wave comes along
-            match_read_rows<W, SCORES, ALL, DEFER>(a, s, sLL, q_pos, q_la, reinterpret_cast<uint32_t *>(stg + ROWBUF_OFF), elig);
+        if (TK == 3) // bucket rows: lookups by lane groups, the whole wave comes along
+            match_read_rows<W, SCORES, ALL, DEFER>(a, s, sLL, stg, elig);
         else if (elig)
             match_read<W, SCORES, ALL, FINE, DEFER>(a, s, sLL, q_pos, q_la, q_cur);
         const bool ovf = DEFER && elig && s.p_n == PEND_OVF;
@@ -1007,8 +1012,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
                     if (SCORES) s.iscore = a.score[r];
                 }
             }
-            if (FINE && a.ix.fine == 3)
-                match_read_rows<W, SCORES, ALL, DEFER>(a, s, sLL, q_pos, q_la, reinterpret_cast<uint32_t *>(stg + ROWBUF_OFF), have);
+            if (TK == 3)
+                match_read_rows<W, SCORES, ALL, DEFER>(a, s, sLL, stg, have);
             else if (have)
                 match_read<W, SCORES, ALL, FINE, DEFER>(a, s, sLL, q_pos, q_la, q_cur);
             if (!have) continue;
@@ -1036,7 +1041,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
 // ---------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------
-template <int W, bool FINE>
+template <int W, int FINE>
 static void launch_match_wf(real_hip_ctx *ctx, const MatchArgs &a, bool all)
 {
     dim3 grid((unsigned)((a.b.n_reads + 255) / 256)), block(256);
@@ -1050,7 +1055,7 @@ static void launch_match_wf(real_hip_ctx *ctx, const MatchArgs &a, bool all)
     }
 }
 // reads the matcher handed over (scores on only): far fewer than the batch, so a fixed grid strides over them
-template <int W, bool FINE>
+template <int W, int FINE>
 static void launch_repeat_wf(real_hip_ctx *ctx, const MatchArgs &a, bool all)
 {
     const uint64_t blocks = (a.b.n_reads + 255) / 256;
@@ -1062,12 +1067,14 @@ template <int W>
 static void launch_match_w(real_hip_ctx *ctx, const MatchArgs &a, bool all, bool repeat)
 {
     if (repeat) {
-        if (a.ix.fine) launch_repeat_wf<W, true>(ctx, a, all);
-        else launch_repeat_wf<W, false>(ctx, a, all);
+        if (a.ix.fine == 3) launch_repeat_wf<W, 3>(ctx, a, all);
+        else if (a.ix.fine) launch_repeat_wf<W, 1>(ctx, a, all);
+        else launch_repeat_wf<W, 0>(ctx, a, all);
         return;
     }
-    if (a.ix.fine) launch_match_wf<W, true>(ctx, a, all);
-    else launch_match_wf<W, false>(ctx, a, all);
+    if (a.ix.fine == 3) launch_match_wf<W, 3>(ctx, a, all);
+    else if (a.ix.fine) launch_match_wf<W, 1>(ctx, a, all);
+    else launch_match_wf<W, 0>(ctx, a, all);
 }
 
 static int launch_match_any(real_hip_ctx *ctx, const MatchArgs &a, bool all, bool repeat)
@@ -1095,7 +1102,7 @@ int rh_launch_match(real_hip_ctx *ctx, const MatchArgs &args, bool all)
     { // reads a wave stages at a time: their bytes (+ alignment skew, pad, one dword of over-read) fit its LDS region
         const uint32_t maxlen = a.b.off ? 32u * a.b.W : a.b.upatl;
         uint32_t gl = 64;
-        while (gl > 1 && (uint64_t)gl * maxlen + STG_PAD + 16 + 16 > stg_bytes((int)a.b.W)) gl >>= 1;
+        while (gl > 1 && (uint64_t)gl * maxlen + STG_PAD + 16 + 16 > stg_bytes((int)a.b.W, (int)a.ix.fine)) gl >>= 1;
         a.b.gl = gl;
     }
     if (sc) { // hand-over list of the reads the matcher leaves to the repeat kernel
