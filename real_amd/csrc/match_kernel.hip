@@ -697,7 +697,7 @@ __device__ __forceinline__ void wave_lds_sync()
 // each), eight lookups per load instruction.  The wave works through its 64 lookups of a list in two halves
 // of 32: four load instructions, the rows go to LDS, then the 32 owner lanes read their row's directory and
 // -- from the same row -- the entries of their key group, apply the partner filter and queue the survivors
-// with their positions.  The loads of the next half are in flight while this one is decoded.  The queue is
+// with their positions.  The loads of the next list are in flight while this one is decoded.  The queue is
 // drained by every lane for itself, in list order, when one is full and at the end.
 template <int W, bool SCORES, bool ALL, bool DEFER, int LA0, int LA1>
 __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL, uint8_t *stg, bool act)
@@ -726,7 +726,7 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
         return v;
     };
     uint32_t qn = 0;
-    uint4 va[8], vb[8];
+    uint4 va[8];
     // the eight loads of list la: lane (8g+j) reads piece j of the row of owner 8*it+g (bucket ~0 = owner takes no part)
     auto issue = [&](int la, uint4 (&v)[8]) {
         const uint32_t bk = act ? (sig_of(la) >> gbits) : 0xffffffffu;
@@ -741,7 +741,6 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
 #pragma unroll 1
     for (int li = 0; li < NL; ++li) { // (a real loop: the drain below must exist once, not NL times)
         const int la = LA0 + li;
-        if (li + 1 < NL) issue(la + 1, vb);
         // rows -> LDS: piece j of row r at r * 128 + ((j ^ (r & 7)) * 16) (16-byte stores; the swizzle spreads the owners'
         // reads of the same dword of different rows over eight bank groups)
         wave_lds_sync();
@@ -751,6 +750,7 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
             *reinterpret_cast<uint4 *>(rowbuf + r * 128 + ((j ^ (r & 7)) * 16)) = va[it];
         }
         wave_lds_sync();
+        if (li + 1 < NL) issue(la + 1, va); // the next list's rows are in flight while this one is decoded and drained
         // owners: directory of the row, then the entries of their key group
         const bool mine = act && !(DEFER && s.p_n == PEND_OVF);
         const uint8_t *rowb = rowbuf + lane * 128;
@@ -828,8 +828,6 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
             if (DEFER && s.p_n == PEND_OVF) e_j = e_cnt;
             if (!__any(e_j < e_cnt)) break;
         }
-#pragma unroll
-        for (int it = 0; it < 8; ++it) va[it] = vb[it];
     }
 }
 
