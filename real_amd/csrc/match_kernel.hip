@@ -274,9 +274,20 @@ __device__ __forceinline__ void flush_pending(const MatchArgs &a, LaneState<W, S
 
 // one member of a bucket whose fingerprint equals the read's: the body of the candidate loop
 // of ::match (match.hpp:383-413)
+// A survivor of the partner filter goes to the lane's queue.  The same window reached through the next list right
+// after (the true locus is found through 4.4 lists per read) only sets that list's bit in the entry: the drain then
+// runs once per window instead of once per (window, list), and the order of the update() events stays the same.
+__device__ __forceinline__ void queue_push(uint32_t *q_pos, uint8_t *q_la, uint32_t &qn, uint32_t pos, int la)
+{
+    if (qn && q_pos[(qn - 1) * 64] == pos) q_la[(qn - 1) * 64] |= (uint8_t)(1u << la);
+    else { q_pos[qn * 64] = pos; q_la[qn * 64] = (uint8_t)(1u << la); qn++; }
+}
+
+// lmask = the lists (bit la) through which this window was reached one right after the other: the window is looked at
+// once, its update() events are delivered list by list
 template <int W, bool SCORES, bool ALL, bool DEFER>
 __device__ __forceinline__ void process_candidate(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL,
-                                                  uint32_t rpos, int la)
+                                                  uint32_t rpos, uint32_t lmask)
 {
     if (SCORES && DEFER && s.p_n == PEND_OVF) return; // handed to the repeat kernel
     const uint64_t *__restrict__ T = a.t.text;
@@ -298,18 +309,20 @@ __device__ __forceinline__ void process_candidate(const MatchArgs &a, LaneState<
         s.crpos = rpos;
     }
     const unsigned k0 = s.ckk & 0xff, k1 = (s.ckk >> 8) & 0xff, k2 = (s.ckk >> 16) & 0xff, k3 = s.ckk >> 24;
-    // the two segments list la is keyed on (s0..s5 = (0,1),(0,2),(0,3),(1,2),(1,3),(2,3))
-    const unsigned ka = (la < 3) ? k0 : (la < 5) ? k1 : k2;
-    const unsigned kc = (la == 0) ? k1 : (la == 1 || la == 3) ? k2 : k3;
-    if (ka | kc) return; // not a member of the reference's equal range (signature wider than prefix+32)
-    if (!a.ix.pbits) s.cC++; // (with partner bits the entry holds the whole signature: counted at the scan)
+    // the lists of lmask of whose equal range the window is a member: both segments the list is keyed on are
+    // mismatch free (s0..s5 = (0,1),(0,2),(0,3),(1,2),(1,3),(2,3)); otherwise the signature is wider than prefix+32
+    const bool z0 = !k0, z1 = !k1, z2 = !k2, z3 = !k3;
+    const uint32_t members = lmask & ((z0 && z1 ? 1u : 0u) | (z0 && z2 ? 2u : 0u) | (z0 && z3 ? 4u : 0u) | (z1 && z2 ? 8u : 0u) |
+                                      (z1 && z3 ? 16u : 0u) | (z2 && z3 ? 32u : 0u));
+    if (!members) return;
+    const uint32_t nm = __popc(members);
+    if (!a.ix.pbits) s.cC += nm; // (with partner bits the entry holds the whole signature: counted at the scan)
     const unsigned seedk = k0 + k1 + k2 + k3; // = diffcountpair(s_b, list_b[p->ptr].sign), match.hpp:386
     if (seedk > a.seedkmax) return;
-    s.cS++;
+    s.cS += nm;
     if (rpos < s.so) return; // match.hpp:393
     const uint32_t pos = rpos - s.so;
     bool reg = false; // a location verified here for the first time
-    uint64_t twl[W];
     if (pos != s.cpos) {
         s.cpos = pos;
         s.cok = false;
@@ -345,41 +358,41 @@ __device__ __forceinline__ void process_candidate(const MatchArgs &a, LaneState<
         float sc = 1.0f; // ComputeScore<...,false>, ComputeScore.hpp:31-45
         if (SCORES && !DEFER)
             sc = score_location<W>(sLL, s.O, tw, s.patl, GlobalRow{a.b.qual + s.o0}, a.b.qual != nullptr, (uint32_t)s.inv);
-        if (SCORES && DEFER) { // the score is computed later: flush_pending
+        s.cok = true; s.ck = total; s.cscore = sc; s.cfrag = frag; s.cslot = SLOT_NONE;
+        if (SCORES && DEFER) { // the score is computed later (flush_pending): park the location
+            if (s.p_n == NPEND) { s.p_n = PEND_OVF; return; } // out of room => the read goes to the repeat kernel
+            const uint32_t meta0 = total | ((uint32_t)s.inv << 8) | (frag << 16);
+            if (s.p_n) { s.p_pos[1] = pos; s.p_meta[1] = meta0; }
+            else {
+                s.p_pos[0] = pos; s.p_meta[0] = meta0;
 #pragma unroll
-            for (int j = 0; j < W; ++j) twl[j] = tw[j];
+                for (int j = 0; j < W; ++j) s.p_tw[j] = tw[j];
+            }
+            s.cslot = s.p_n++;
             reg = true;
         }
-        s.cok = true; s.ck = total; s.cscore = sc; s.cfrag = frag; s.cslot = SLOT_NONE;
     }
+    (void)reg;
     if (!s.cok) return;
-    s.cH++; // one updater::update call, match.hpp:411
-    bool emit = true;
+    s.cH += nm; // one updater::update call per list, match.hpp:411
+    uint32_t events = members;
     if (ALL) {
         // unifyMatches (matchAllImplementation.cpp:150-161) only removes exact duplicates: the same
-        // (strand,pos) reached through a later list.  A hit is kept iff la is the first list whose two
-        // segments are mismatch free.
-        const bool z0 = !k0, z1 = !k1, z2 = !k2, z3 = !k3;
+        // (strand,pos) reached through a later list.  A hit is kept iff it comes from the first list whose
+        // two segments are mismatch free.
         const int first = (z0 && z1) ? 0 : (z0 && z2) ? 1 : (z0 && z3) ? 2 : (z1 && z2) ? 3 : (z1 && z3) ? 4 : 5;
-        emit = (first == la);
+        events &= 1u << first;
     }
     const uint32_t meta = s.ck | ((uint32_t)s.inv << 8) | (s.cfrag << 16);
+    const uint32_t ne = __popc(events);
     if (!(SCORES && DEFER)) {
-        if (emit) deliver<W, SCORES, ALL>(a, s, s.cpos, meta, s.cscore);
+        for (uint32_t e = 0; e < ne; ++e) deliver<W, SCORES, ALL>(a, s, s.cpos, meta, s.cscore);
         return;
     }
-    // park the location (once) and the event; out of room => the read goes to the repeat kernel
-    if ((reg && s.p_n == NPEND) || (emit && s.p_nev == PEND_EV)) { s.p_n = PEND_OVF; return; }
-    if (reg) {
-        if (s.p_n) { s.p_pos[1] = s.cpos; s.p_meta[1] = meta; }
-        else {
-            s.p_pos[0] = s.cpos; s.p_meta[0] = meta;
-#pragma unroll
-            for (int j = 0; j < W; ++j) s.p_tw[j] = twl[j];
-        }
-        s.cslot = s.p_n++;
-    }
-    if (emit) { s.p_ev |= s.cslot << s.p_nev; s.p_nev++; }
+    // park the events (they all refer to the memo's slot); out of room => the read goes to the repeat kernel
+    if (s.p_nev + ne > PEND_EV) { s.p_n = PEND_OVF; return; }
+    if (s.cslot) s.p_ev |= ((ne >= 32 ? 0xffffffffu : ((1u << ne) - 1u)) << s.p_nev);
+    s.p_nev += ne;
 }
 
 // Scan of the buckets of lists [LA0, LA1) of one strand; pushes the entries that survive the key
@@ -478,11 +491,7 @@ __device__ __forceinline__ bool scan_lists(const MatchArgs &a, LaneState<W, SCOR
                         const uint32_t x = (e.x & pmask) ^ rp;
                         keep = __popc(((x >> 1) | x) & 0x55555555u) <= a.seedkmax;
                     }
-                    if (keep) {
-                        q_pos[qn * 64] = e.y;
-                        q_la[qn * 64] = (uint8_t)(LA0 + i);
-                        qn++;
-                    }
+                    if (keep) queue_push(q_pos, q_la, qn, e.y, LA0 + i);
                 }
                 j++;
             }
@@ -634,16 +643,14 @@ __device__ __forceinline__ void match_lists_fine(const MatchArgs &a, LaneState<W
                     // only be larger)
                     const uint32_t x = (e[u].x & pmask) ^ r;
                     if (fpk ? (e[u].x == r) : (__popc(((x >> 1) | x) & 0x55555555u) <= a.seedkmax)) {
-                        q_pos[qn * 64] = e[u].y;
-                        q_la[qn * 64] = (uint8_t)(LA0 + li[u]);
-                        qn++;
+                        queue_push(q_pos, q_la, qn, e[u].y, LA0 + (int)li[u]);
                     }
                 }
             }
         }
         // 3. verify / score / fold in candidate order
         for (uint32_t k = 0; k < qn; ++k)
-            process_candidate<W, SCORES, ALL, DEFER>(a, s, sLL, q_pos[k * 64], (int)q_la[k * 64]);
+            process_candidate<W, SCORES, ALL, DEFER>(a, s, sLL, q_pos[k * 64], (uint32_t)q_la[k * 64]);
     }
 }
 
@@ -657,11 +664,11 @@ __device__ __forceinline__ void match_lists(const MatchArgs &a, LaneState<W, SCO
     bool again = scan_lists<W, SCORES, ALL, FINE, LA0, LA1, true>(a, s, q_pos, q_la, q_cur, donemask, qn);
     // 4. verify / score / fold in candidate order
     for (uint32_t k = 0; k < qn; ++k)
-        process_candidate<W, SCORES, ALL, DEFER>(a, s, sLL, q_pos[k * 64], (int)q_la[k * 64]);
+        process_candidate<W, SCORES, ALL, DEFER>(a, s, sLL, q_pos[k * 64], (uint32_t)q_la[k * 64]);
     while (again) {
         again = scan_lists<W, SCORES, ALL, FINE, LA0, LA1, false>(a, s, q_pos, q_la, q_cur, donemask, qn);
         for (uint32_t k = 0; k < qn; ++k)
-            process_candidate<W, SCORES, ALL, DEFER>(a, s, sLL, q_pos[k * 64], (int)q_la[k * 64]);
+            process_candidate<W, SCORES, ALL, DEFER>(a, s, sLL, q_pos[k * 64], (uint32_t)q_la[k * 64]);
     }
 }
 
@@ -817,13 +824,13 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
                 }
                 // seed popcount filter (match.hpp:386) on the partner symbols the entry carries: more than seedkmax
                 // known mismatches => rejected without touching the text (exact: the full count can only be larger)
-                if (pass) { q_pos[qn * 64] = pos; q_la[qn * 64] = (uint8_t)la; qn++; }
+                if (pass) queue_push(q_pos, q_la, qn, pos, la);
                 e_j++;
             }
             if (!__any(e_j < e_cnt) && li + 1 < NL) break;
             // a full queue somewhere, or the end of the lists: verify / score / fold in candidate order
             for (uint32_t k = 0; k < qn; ++k)
-                process_candidate<W, SCORES, ALL, DEFER>(a, s, sLL, q_pos[k * 64], (int)q_la[k * 64]);
+                process_candidate<W, SCORES, ALL, DEFER>(a, s, sLL, q_pos[k * 64], (uint32_t)q_la[k * 64]);
             qn = 0;
             if (DEFER && s.p_n == PEND_OVF) e_j = e_cnt;
             if (!__any(e_j < e_cnt)) break;
