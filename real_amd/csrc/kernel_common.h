@@ -112,8 +112,7 @@ __device__ __forceinline__ unsigned long long wave_append_slot(unsigned long lon
 }
 
 // two consecutive u64 with one 16-byte request.  The address is only 8-byte aligned: global loads
-// need dword alignment on gfx950, and one request instead of two matters here -- the matcher is bound
-// by the number of memory requests it issues, not by bytes.
+// need dword alignment on gfx950, and one request instead of two keeps the vector-memory pipeline short.
 struct __attribute__((packed, aligned(8))) U64x2 { uint64_t a, b; };
 __device__ __forceinline__ U64x2 load2(const uint64_t *__restrict__ p) { return *reinterpret_cast<const U64x2 *>(p); }
 

@@ -1,5 +1,7 @@
 // match_kernel.hip -- the per-read matcher of REAL as one hand-written gfx950 kernel
-// (SURVEY 8a rows a6..a12):
+// (SURVEY 8a rows a1..a12):
+//   read symbols, eligibility, signatures   Pattern.hpp:105-128, matchUniqueImplementation.cpp:376-394,
+//                                           SignatureConstruction.hpp:62-67, 218-280, 347-410
 //   bucket lookup + in-bucket search        match.hpp:376-381
 //   seed popcount filter                    match.hpp:383-388, PopCountTable.hpp:113-131
 //   position / fragment / N checks          match.hpp:390-398
@@ -8,21 +10,25 @@
 //   best/unique fold                        matchUniqueImplementation.cpp:97-160, 179-248
 //   or hit append of matchAll               matchAllImplementation.cpp:172-184
 //
-// Work decomposition: one lane per read, 256-thread workgroups.  For each strand the lane
-//   1. issues the bucket-table loads of all lists of the strand together,
-//   2. issues the loads of the first two entries of every bucket together,
-//   3. scans the buckets in list order and pushes the entries whose fingerprint matches
-//      into a small per-lane queue in LDS (list-major, entry order = the reference's
-//      candidate order),
-//   4. drains the queue in order: seed window from the 2-bit text, popcount filters, whole
-//      read Hamming distance, score, and the fold (or the matchAll append).
-// The update() events of a read therefore reach the fold in the canonical order (strand,
-// list, position), which matters because the fold is order dependent when scores are on
-// (SURVEY 8a10).  Every memory access of the kernel is a dependent random 8..40-byte read of
-// an HBM-resident table: the kernel is bound by the number of dependent round trips a wave
-// makes and by HBM sector throughput, not by arithmetic (no MFMA: XOR/popcount and a short
-// FP64 add chain).  Batching the loads (steps 1, 2) and queueing the candidates (step 3)
-// are what keep the number of sequential round trips per wave small.
+// Work decomposition: one lane per read, 256-thread workgroups, three waves per SIMD.
+//   front  the wave copies the bases of its 64 reads (one contiguous range of the caller's array) into its
+//          LDS region; every lane packs its own read into registers (32 bases per word), derives the seed
+//          halves of both strands; the reverse complement is computed in registers.
+//   match  per strand: the bucket-table entries of the six lists are requested together; the equal ranges
+//          are enumerated in list order and the entries that survive the partner filter go to the lane's
+//          queue in LDS (list-major, entry order = the reference's candidate order; a window reached
+//          through consecutive lists is one entry with a list mask); the queue is drained in order: seed
+//          window from the 2-bit text, popcount filters, whole-read Hamming distance.  With scores on a
+//          verified window and its update() events are parked.  Three table kinds feed this stage
+//          (match_lists: bucket starts; match_lists_fine: directory entries with partner digests or key
+//          fingerprints) and a fourth replaces it by lookups of lane groups (match_lists_rows).
+//   back   the wave copies the qualities of its reads through LDS the same way; all lanes score their
+//          parked windows together and replay their events into the fold / append them for matchAll.
+// The update() events of a read reach the fold in the canonical order (strand, list, position), which
+// matters because the fold is order dependent when scores are on.  Every index access is a
+// dependent random 8..48-byte read of a 128-byte line of an HBM-resident table: the kernel is bound by
+// the HBM lines it moves (20.7 per read with digest tables, 95 % of the sustainable line rate), not by
+// arithmetic (no MFMA: XOR/popcount and a short FP64 add chain).
 #include "kernel_common.h"
 
 #define EB 8  // index entries a lane requests per round trip while enumerating equal ranges
