@@ -38,11 +38,12 @@
 // the batch.  9.5 KiB hold the 64 reads of a wave up to 151 bases each in one go; with the 8 KiB score table that
 // is 46 KiB per workgroup = three workgroups per CU, which is what the registers allow anyway.
 #define QUEUE_BYTES (MQ * 64u * 5u + 6u * 64u * 4u)
-__host__ __device__ constexpr uint32_t stg_bytes(int W, int TK) { return TK == 3 ? 10752u : (W <= 4 ? QUEUE_BYTES : 9728u); }
+__host__ __device__ constexpr uint32_t stg_bytes(int W, int TK) { return TK == 3 ? 11008u : (W <= 4 ? QUEUE_BYTES : 9728u); }
 // bucket rows (table kind 3): a queue of MQR slots per lane, then the 64 rows of a list, 128 bytes each
 #define MQR 8u
 #define ROWBUF_OFF (MQR * 64u * 5u)
-static_assert(ROWBUF_OFF + 64u * 128u <= stg_bytes(4, 3) && ROWBUF_OFF % 16 == 0 && QUEUE_BYTES % 16 == 0, "row staging fits the wave's LDS region");
+#define BKX_OFF (ROWBUF_OFF + 64u * 128u) /* 64 bucket numbers, transposed for the piece loaders */
+static_assert(BKX_OFF + 256u <= stg_bytes(4, 3) && ROWBUF_OFF % 16 == 0 && QUEUE_BYTES % 16 == 0, "row staging fits the wave's LDS region");
 #define STG_PAD 16u
 #define NPEND 2      // verified locations a lane parks until their scores are computed (flush_pending)
 #define PEND_EV 32   // update() events parked with them
@@ -724,46 +725,53 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
     const uint32_t bb = a.b_bits;
     const uint32_t gbits = a.ix.fbits, pbits = a.ix.pbits, p16 = pbits < 16 ? pbits : 16;
     const uint32_t pmask = (1u << pbits) - 1;
-    // the six signatures of the strand (32 bits: seedl <= 32); the partner of list k is list 5-k
-    uint32_t sig[6];
+    // the four seed segments of the strand in 16-bit fields (seedl <= 32: a segment has at most 16 bits); the
+    // signature of list la is two of them (SignatureConstruction.hpp:62-67), picked with shifts -- an array
+    // indexed by the (uniform, run-time) list number would live in scratch memory
+    uint64_t M;
     {
         const uint32_t mb = (1u << bb) - 1;
-        const uint32_t m0 = (uint32_t)(s.shi >> bb), m1 = (uint32_t)s.shi & mb, m2 = (uint32_t)(s.slo >> bb), m3 = (uint32_t)s.slo & mb;
-        sig[0] = (m0 << bb) | m1; sig[1] = (m0 << bb) | m2; sig[2] = (m0 << bb) | m3; // SignatureConstruction.hpp:62-67
-        sig[3] = (m1 << bb) | m2; sig[4] = (m1 << bb) | m3; sig[5] = (m2 << bb) | m3;
+        M = ((uint64_t)(uint32_t)(s.shi >> bb) << 48) | ((uint64_t)((uint32_t)s.shi & mb) << 32) | ((uint64_t)(uint32_t)(s.slo >> bb) << 16) |
+            (uint64_t)((uint32_t)s.slo & mb);
     }
-    auto sig_of = [&](int la) {
-        uint32_t v = sig[0];
-#pragma unroll
-        for (int i = 1; i < 6; ++i) if (la == i) v = sig[i];
-        return v;
+    auto sig_of = [&](int la) { // s0..s5 = segments (0,1),(0,2),(0,3),(1,2),(1,3),(2,3)
+        const uint32_t xa = (0x940u >> (2 * la)) & 3u, xc = (0xfb9u >> (2 * la)) & 3u;
+        return (((uint32_t)(M >> (48 - 16 * xa)) & 0xffffu) << bb) | ((uint32_t)(M >> (48 - 16 * xc)) & 0xffffu);
     };
     uint32_t qn = 0;
-    uint4 va[8];
-    // the eight loads of list la: lane (8g+j) reads piece j of the row of owner 8*it+g (bucket ~0 = owner takes no part)
-    auto issue = [&](int la, uint4 (&v)[8]) {
-        const uint32_t bk = act ? (sig_of(la) >> gbits) : 0xffffffffu;
-        const uint4 *__restrict__ R = reinterpret_cast<const uint4 *>(a.ix.bkt[la]);
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const uint32_t ob = __shfl(bk, 8 * it + (int)(lane >> 3));
-            v[it] = (ob != 0xffffffffu) ? R[(uint64_t)ob * 8 + (lane & 7)] : make_uint4(0, 0, 0, 0);
-        }
-    };
-    issue(LA0, va);
+    uint4 va0, va1, va2, va3, va4, va5, va6, va7; // (eight scalars, not an array: the array went through scratch memory)
+    uint32_t *bkx = reinterpret_cast<uint32_t *>(stg + BKX_OFF);
+    // the eight loads of list la: lane (8g+j) reads piece j of the row of owner 8*it+g.  The owners' bucket numbers go
+    // through LDS transposed, so that a loader finds its eight at bkx[8g .. 8g+7] (an owner that takes no part: row 0)
+    // (a macro, not a lambda taking the array by reference: that sent the eight rows through scratch memory)
+#define ISSUE_ROWS(LA)                                                                                                      \
+    do {                                                                                                                    \
+        bkx[(lane & 7) * 8 + (lane >> 3)] = act ? (sig_of(LA) >> gbits) : 0u;                                              \
+        __builtin_amdgcn_wave_barrier(); /* LDS operations of a wave execute in order; a fence would also wait for loads */ \
+        const uint4 b0_ = *reinterpret_cast<const uint4 *>(bkx + (lane >> 3) * 8);                                          \
+        const uint4 b1_ = *reinterpret_cast<const uint4 *>(bkx + (lane >> 3) * 8 + 4);                                      \
+        const uint4 *__restrict__ R_ = reinterpret_cast<const uint4 *>(a.ix.bkt[LA]) + (lane & 7);                          \
+        va0 = R_[(uint64_t)b0_.x * 8]; va1 = R_[(uint64_t)b0_.y * 8]; va2 = R_[(uint64_t)b0_.z * 8];                        \
+        va3 = R_[(uint64_t)b0_.w * 8]; va4 = R_[(uint64_t)b1_.x * 8]; va5 = R_[(uint64_t)b1_.y * 8];                        \
+        va6 = R_[(uint64_t)b1_.z * 8]; va7 = R_[(uint64_t)b1_.w * 8];                                                       \
+    } while (0)
+    ISSUE_ROWS(LA0);
 #pragma unroll 1
     for (int li = 0; li < NL; ++li) { // (a real loop: the drain below must exist once, not NL times)
         const int la = LA0 + li;
         // rows -> LDS: piece j of row r at r * 128 + ((j ^ (r & 7)) * 16) (16-byte stores; the swizzle spreads the owners'
         // reads of the same dword of different rows over eight bank groups)
         wave_lds_sync();
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const uint32_t r = 8 * it + (lane >> 3), j = lane & 7;
-            *reinterpret_cast<uint4 *>(rowbuf + r * 128 + ((j ^ (r & 7)) * 16)) = va[it];
+        {
+            // lane (8g+j) holds piece j of the rows 8*it+g: (8*it+g) & 7 == g, so the swizzle does not depend on it
+            uint8_t *d = rowbuf + (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) * 16);
+            *reinterpret_cast<uint4 *>(d + 0 * 1024) = va0; *reinterpret_cast<uint4 *>(d + 1 * 1024) = va1;
+            *reinterpret_cast<uint4 *>(d + 2 * 1024) = va2; *reinterpret_cast<uint4 *>(d + 3 * 1024) = va3;
+            *reinterpret_cast<uint4 *>(d + 4 * 1024) = va4; *reinterpret_cast<uint4 *>(d + 5 * 1024) = va5;
+            *reinterpret_cast<uint4 *>(d + 6 * 1024) = va6; *reinterpret_cast<uint4 *>(d + 7 * 1024) = va7;
         }
         wave_lds_sync();
-        if (li + 1 < NL) issue(la + 1, va); // the next list's rows are in flight while this one is decoded and drained
+        if (li + 1 < NL) ISSUE_ROWS(la + 1); // the next list's rows are in flight while this one is decoded and drained
         // owners: directory of the row, then the entries of their key group
         const bool mine = act && !(DEFER && s.p_n == PEND_OVF);
         const uint8_t *rowb = rowbuf + lane * 128;
