@@ -57,7 +57,7 @@ typedef struct real_hip_params {
                                (The reference's 22-bit getSampleBits() table is a
                                host-layout detail; results do not depend on it.)      */
     int32_t  device;        /* HIP device ordinal                                     */
-    uint32_t table_kind;    /* device bucket tables: 0 = auto from index size, 1 = bucket starts only,
+    uint32_t table_kind;    /* device bucket tables: 0 = auto from index size and device memory, 1 = bucket starts only,
                                2 = directory entries (group sizes + partner digests for seedl <= 32,
                                key fingerprints for wider signatures), 3 = bucket rows (seedl <= 32: one 128-byte
                                row per bucket holds directory and entries, lookups by groups of eight

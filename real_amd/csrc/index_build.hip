@@ -94,6 +94,18 @@ void rh_choose_tables(real_hip_ctx *ctx, uint64_t n_entries)
     uint32_t lg = 0;
     while ((1ull << (lg + 1)) <= (n_entries ? n_entries : 1)) lg++;
     const bool big = lg >= 27 && want != 1;
+    bool rows = want == 3;
+    if (want == 0 && auto_pb && big && l <= 32 && !ctx->no_rows) {
+        // bucket rows are the faster layout (one HBM line per lookup) when they fit: 128 B x 2^pb x 6 lists plus the
+        // build's transients (the full entry array of one list, the window positions, the bucket starts and overflow scans)
+        uint32_t rpb = 1;
+        while (rpb < 30 && (double)n_entries / (double)(1ull << rpb) > 11.5) rpb++;
+        if (rpb + 4 < l) rpb = l - 4;
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        const double need = 6.0 * 128.0 * (double)(1ull << rpb) + 12.0 * (double)n_entries + 12.0 * (double)(1ull << rpb);
+        rows = rpb < l && need * 1.08 <= (double)total_b;
+    }
     if (auto_pb) {
         if (l <= 32 && big) {
             // large index, 32-bit signatures: prefix = all signature bits but three ("fine" tables: the bucket
@@ -110,7 +122,7 @@ void rh_choose_tables(real_hip_ctx *ctx, uint64_t n_entries)
             if (pb < 8) pb = 8;
         }
     }
-    if (want == 3 && auto_pb && l <= 32) {
+    if (rows && auto_pb && l <= 32) {
         // bucket rows: about 11 entries per 128-byte row of 20, at most 16 signature values per row
         pb = 1;
         while (pb < 30 && (double)n_entries / (double)(1ull << pb) > 11.5) pb++;
@@ -124,7 +136,7 @@ void rh_choose_tables(real_hip_ctx *ctx, uint64_t n_entries)
     uint32_t pshift, fshift, fbits, pbits;
     rh_index_geometry(l, pb, &pshift, &fshift, &fbits, &pbits);
     if (want == 1) ctx->fine = 0;
-    else if (want == 3 && l <= 32 && l >= pb && l - pb >= 1 && l - pb <= 4) ctx->fine = 3;
+    else if (rows && l <= 32 && l >= pb && l - pb >= 1 && l - pb <= 4) ctx->fine = 3;
     else if (rh_is_fine(l, pb)) ctx->fine = 1;
     else if (pbits == 0 && (want == 2 || (auto_pb && big))) ctx->fine = 2;
     else ctx->fine = 0;
@@ -559,6 +571,15 @@ int rh_index_build_device(real_hip_ctx *ctx, uint64_t first_window, uint64_t max
     rh_choose_tables(ctx, cnt);
     for (int k = 0; k < 6; ++k) {
         rc = (l <= 32) ? sort_list<uint32_t>(ctx, k, d_wpos, cnt) : sort_list<uint64_t>(ctx, k, d_wpos, cnt);
+        if (rc == REAL_HIP_E_NOMEM && ctx->fine == 3 && ctx->prm.table_kind == 0 && !ctx->no_rows) {
+            // the rows did not fit after all (memory held by others): once more with directory tables
+            for (int j = 0; j < 6; ++j) { rh_release(ctx->ent[j]); rh_release(ctx->bkt[j]); }
+            rh_release(ctx->keys_a); rh_release(ctx->keys_b); rh_release(ctx->vals_b); rh_release(ctx->sort_tmp);
+            ctx->no_rows = true;
+            rh_choose_tables(ctx, cnt);
+            k = -1;
+            continue;
+        }
         if (rc) return rc;
     }
     RH_HIP(ctx, hipStreamSynchronize(ctx->stream));

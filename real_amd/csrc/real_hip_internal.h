@@ -125,6 +125,7 @@ struct real_hip_ctx {
     uint64_t n_entries = 0;
     uint32_t pb = 0;
     int fine = 0;      // bucket table kind, see DevIndex::fine
+    bool no_rows = false; // bucket rows did not fit the device memory once: stay with directory tables
     bool have_index = false;
 
     // tables / counters
