@@ -793,18 +793,21 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
                 e_base = __builtin_amdgcn_sad_u8(b0, 0u, __builtin_amdgcn_sad_u8(b1, 0u, 0u));
             } else { // complex bucket: its entries are in the overflow array; 8-bit group counts
                 e_ovf = true;
-                uint32_t off = 0;
-                bool sat = false;
+                // sixteen 8-bit counts in four words: the sum of those in front of mine, mine, and whether any of them
+                // is saturated (byte-parallel: this branch runs whenever one of the 64 lanes meets such a bucket)
+                uint32_t off = 0, sat255 = 0;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const uint32_t w = row(4 + q);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const uint32_t c8 = (w >> (8 * t)) & 255u, gi = 4 * q + t;
-                        if (gi < g) { off += c8; sat = sat || c8 == 255u; }
-                        if (gi == g) { e_cnt = c8; sat = sat || c8 == 255u; }
-                    }
+                    const int nb = (int)g - 4 * q;                                     // counts of this word in front of mine
+                    const uint32_t below = nb <= 0 ? 0u : (nb >= 4 ? 0xffffffffu : ((1u << (8 * nb)) - 1u));
+                    const uint32_t upto = nb < 0 ? 0u : (nb >= 3 ? 0xffffffffu : ((1u << (8 * (nb + 1))) - 1u)); // ... and mine
+                    off = __builtin_amdgcn_sad_u8(w & below, 0u, off);
+                    if ((g >> 2) == (uint32_t)q) e_cnt = (w >> (8 * (g & 3))) & 255u;
+                    const uint32_t y = ~w | ~upto;                                     // a zero byte = a count of 255 among them
+                    sat255 |= (y - 0x01010101u) & ~y & 0x80808080u;
                 }
+                const bool sat = sat255 != 0;
                 const uint32_t o0 = row(2), tot = row(3);
                 e_base = o0 + off;
                 if (sat) { // a group of 255 or more entries in front of / at the key: bounds by binary search

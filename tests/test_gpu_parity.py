@@ -199,6 +199,28 @@ def test_match_all_many_hits_per_read(ora, scores, rows):
     m.close()
 
 
+@pytest.mark.parametrize("kind,pb", [(3, 4), (3, 7), (0, 7), (0, 0)])
+def test_saturated_key_groups(ora, kind, pb):
+    # a 3 kbp tandem repeat of period 10 and 8-base seeds: a handful of signatures with 300 entries each -- the 8-bit /
+    # 4-bit group counts of the bucket rows / directory tables saturate and the bounds come from the binary search
+    g = synth.random_genome(3000, seed=61)
+    rng = np.random.default_rng(62)
+    unit = rng.integers(0, 4, size=10, dtype=np.uint8)
+    g.sym[:] = np.where(rng.random(3000) < 0.01, rng.integers(0, 4, size=3000, dtype=np.uint8), np.tile(unit, 300))
+    b = synth.sample_reads(g, 200, 24, 0.03, seed=63)
+    p = ora.make_params(seedl=8, seedkmax=2, totalkmax=3, scores=1)
+    oinfo, oscore, octr = _oracle_unique(ora, None, g.sym, g.frag_start, 8, 0, p, b.bases, b.qual, b.offsets)
+    m = UniqueMatcher(_opts(8, 2, 3, 1), prefix_bits=pb, table_kind=kind)
+    m.set_text_symbols(0, g.sym, g.frag_start)
+    m.build_index_block()
+    info, score = m.match_unique(b.bases, b.qual, b.offsets)
+    _compare_unique(info, score, oinfo, oscore, 1)
+    c = m.counters()
+    for kk in ("reads", "lookups", "candidates", "seedpass", "hits"):
+        assert c[kk] == octr[kk], (kk, c[kk], octr[kk])
+    m.close()
+
+
 def test_index_layout_device_equals_host(ora):
     g = synth.random_genome(50_000, seed=77, n_frag=3, n_runs=10, repeats=10)
     for seedl, kw in ((32, {}), (64, {}), (12, {}), (16, dict(table_kind=3, prefix_bits=12)), (16, dict(table_kind=3))):
