@@ -79,6 +79,7 @@ RealOptions::RealOptions(int argc, char *argv[])
         else if (a == "-batch") { batch_reads = strtoull(need("-batch").c_str(), 0, 10); i += 2; }
         else if (a == "-prefix_bits") { prefix_bits = atoi(need("-prefix_bits").c_str()); i += 2; }
         else if (a == "-gpuparse") { gpuparse = atoi(need("-gpuparse").c_str()); i += 2; }
+        else if (a == "-table_kind") { table_kind = atoi(need("-table_kind").c_str()); i += 2; }
         else if (a == "-h") { printHelp(); i += 1; }
         else { std::cerr << "Ignoring unknown argument " << a << std::endl; i += 1; }
     }

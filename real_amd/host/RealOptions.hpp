@@ -28,6 +28,7 @@ struct RealOptions {
     uint64_t block_entries = 0; // -block: positions per index block (0 = as many as fit)
     uint64_t batch_reads = 4u << 20; // -batch: reads per device batch
     unsigned prefix_bits = 0;
+    unsigned table_kind = 0;         // -table_kind: device bucket tables (real_hip.h), 0 = auto
     unsigned gpuparse = 1;           // -gpuparse: parse the read file on the device when it is in one-line-per-field form
 
     RealOptions() {}

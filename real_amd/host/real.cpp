@@ -50,7 +50,7 @@ std::vector<std::unique_ptr<Ctx>> makeContexts(const RealOptions &o)
     memset(&p, 0, sizeof p);
     p.struct_size = sizeof p;
     p.seedl = o.seedl; p.seedkmax = o.seedkmax; p.totalkmax = o.totalkmax; p.scores = o.scores;
-    p.prefix_bits = o.prefix_bits; p.filter_mult = o.filter_mult;
+    p.prefix_bits = o.prefix_bits; p.table_kind = o.table_kind; p.filter_mult = o.filter_mult;
     real_hip_scoring_table(o.similarity, o.gc, o.trans, o.err, o.gcmut_bias, p.LL); // Scoring(opts...) :1115
     std::vector<std::unique_ptr<Ctx>> v;
     for (int g = 0; g < o.gpus; ++g) {

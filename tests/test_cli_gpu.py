@@ -67,6 +67,7 @@ def oracle_unique(ora, g, b, seedl, seedk, totalk, scores, n_list=0, fasta=False
     (1, ["-block", "30000", "-batch", "500"], 30000, True),      # three index blocks, several read batches
     (1, [], 0, False),                                             # FASTA reads: constant quality 30
     (1, ["-gpuparse", "0"], 0, True),                              # read file parsed by the host reader
+    (1, ["-table_kind", "3", "-l", "16", "-prefix_bits", "13"], 0, True),   # bucket rows (seed length 16 so that they are small)
     (1, ["-wrap"], 0, False),                                      # wrapped FASTA: the device parser refuses, host reader takes over
 ])
 def test_real_cli_match_unique(ora, tmp_path, scores, extra, n_list, fastq):
@@ -82,7 +83,8 @@ def test_real_cli_match_unique(ora, tmp_path, scores, extra, n_list, fastq):
     cmd = [REAL, "-t", fa, "-p", rd, "-o", out, "-e", "3", "-s", "2", "-l", "32", "-q", str(scores)] + extra
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
-    info, score = oracle_unique(ora, g, b, 32, 2, 3, scores, n_list, fasta=not fastq)
+    seedl = int(extra[extra.index("-l") + 1]) if "-l" in extra else 32       # (a later -l overrides the one above)
+    info, score = oracle_unique(ora, g, b, seedl, 2, 3, scores, n_list, fasta=not fastq)
     want = expected_unique(ora, g, b, info, score, scores)
     got = open(out).read().split("\n")[:-1]
     assert len(got) == len(want)
