@@ -221,6 +221,37 @@ def test_saturated_key_groups(ora, kind, pb):
     m.close()
 
 
+@pytest.mark.parametrize("kind,pb,device_build", [(3, 13, True), (3, 13, False), (2, 13, True), (0, 0, True)])
+def test_index_blocks_compose(ora, kind, pb, device_build):
+    # the genome in three index blocks (ListSetBlockReader.hpp:24-52): the records fold across the blocks exactly as the
+    # reference's uniqueinfo[] does; every block rebuilds the resident tables (rows, directory, starts) in place
+    g = synth.random_genome(90_000, seed=71, n_frag=2, n_runs=4, repeats=12)
+    b = synth.sample_reads(g, 3000, 60, 0.02, seed=72)
+    n_list = 32_000
+    p = ora.make_params(seedl=16, seedkmax=2, totalkmax=3, scores=1)
+    oinfo, oscore, _ = _oracle_unique(ora, None, g.sym, g.frag_start, 16, n_list, p, b.bases, b.qual, b.offsets)
+    m = UniqueMatcher(_opts(16, 2, 3, 1), prefix_bits=pb, table_kind=kind)
+    if device_build:
+        m.set_text_symbols(0, g.sym, g.frag_start)
+    else:
+        text, wild = host_index.pack_text(g.sym)
+        m.set_text(0, text, wild, g.n, g.frag_start)
+    info = score = None
+    first, nxt, blocks = 0, True, 0
+    while nxt:
+        if device_build:
+            n, nxt = m.build_index_block(first, n_list)
+        else:
+            sign, pos, n, nxt = host_index.build_lists(g.sym, 16, first, n_list)
+            m.set_index_block(sign, pos)
+        first += n
+        blocks += 1
+        info, score = m.match_unique(b.bases, b.qual, b.offsets, info=info, score=score)
+    assert blocks == 3
+    _compare_unique(info, score, oinfo, oscore, 1)
+    m.close()
+
+
 def test_index_layout_device_equals_host(ora):
     g = synth.random_genome(50_000, seed=77, n_frag=3, n_runs=10, repeats=10)
     for seedl, kw in ((32, {}), (64, {}), (12, {}), (16, dict(table_kind=3, prefix_bits=12)), (16, dict(table_kind=3))):
