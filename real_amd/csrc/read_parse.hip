@@ -145,10 +145,9 @@ __global__ void record_spans_kernel(const char *__restrict__ text, const uint32_
     if ((threadIdx.x & 63) == 0 && mylen > *(volatile unsigned int *)max_len) atomicMax(max_len, mylen);
 }
 
-// one wave per 64 records: their symbols and qualities go to one contiguous range of the batch arrays; the wave
-// walks its records one after the other and its lanes take consecutive bytes, so every load and store is a
-// coalesced run of the record's bytes
-__global__ __launch_bounds__(256) void record_gather_kernel(const char *__restrict__ text, uint64_t n_rec,
+// byte-wide variant (text at an address that is not a multiple of four): one wave per 64 records, the wave walks its
+// records one after the other and its lanes take consecutive bytes
+__global__ __launch_bounds__(256) void record_gather_bytes_kernel(const char *__restrict__ text, uint64_t n_rec,
                                                             const uint32_t *__restrict__ seq_start, const uint32_t *__restrict__ qual_start,
                                                             const uint64_t *__restrict__ off, int fastq, int qoff, uint8_t *__restrict__ bases,
                                                             uint8_t *__restrict__ qual, unsigned int *__restrict__ bad)
@@ -189,6 +188,98 @@ __global__ __launch_bounds__(256) void record_gather_kernel(const char *__restri
             space = space || c[u] == ' ' || (c[u] >= '\t' && c[u] <= '\r') || d[u] == ' ' || (d[u] >= '\t' && d[u] <= '\r'); // isspace: the reference would skip it
             bases[dst[u]] = v;
             if (fastq) qual[dst[u]] = (uint8_t)(d[u] - qoff);
+        }
+    }
+    if (space) atomicOr(bad, 4u);
+}
+
+// one wave per 64 records: their symbols and qualities go to one contiguous range of the batch arrays.  A record is
+// handled by LPR lanes (32 for reads up to 128 bases, else 64), four bytes per lane: two aligned dword loads and a
+// byte funnel bring the lane's four characters, they are mapped and stored as one dword where the destination allows
+// it.  Four work items (record pairs x 4*LPR-byte chunks) are in flight before their stores.
+__device__ __forceinline__ uint32_t map4(uint32_t x, bool &space)
+{
+    uint32_t out = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const uint32_t c = (x >> (8 * b)) & 0xffu;
+        const uint32_t v = c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u;
+        space = space || c == ' ' || (c >= '\t' && c <= '\r'); // isspace: the reference would skip it
+        out |= v << (8 * b);
+    }
+    return out;
+}
+__device__ __forceinline__ uint32_t sub4(uint32_t x, uint32_t qoff, bool &space)
+{
+    uint32_t out = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const uint32_t c = (x >> (8 * b)) & 0xffu;
+        space = space || c == ' ' || (c >= '\t' && c <= '\r');
+        out |= ((c - qoff) & 0xffu) << (8 * b);
+    }
+    return out;
+}
+// the four bytes at text + at (text 4-byte aligned); bytes at or behind n_bytes read as 0
+__device__ __forceinline__ uint32_t load4(const char *__restrict__ text, uint64_t at, uint64_t n_bytes)
+{
+    const uint64_t a = at & ~(uint64_t)3;
+    if (a + 8 <= n_bytes) {
+        const uint32_t w0 = *reinterpret_cast<const uint32_t *>(text + a), w1 = *reinterpret_cast<const uint32_t *>(text + a + 4);
+        return __builtin_amdgcn_alignbyte(w1, w0, (uint32_t)at & 3u);
+    }
+    uint32_t v = 0; // the last bytes of the text
+    for (uint32_t b = 0; b < 4; ++b)
+        if (at + b < n_bytes) v |= (uint32_t)(uint8_t)text[at + b] << (8 * b);
+    return v;
+}
+__device__ __forceinline__ void store4(uint8_t *__restrict__ dst, uint64_t at, uint32_t v, uint32_t nvalid)
+{
+    if (nvalid >= 4 && (at & 3) == 0) { *reinterpret_cast<uint32_t *>(dst + at) = v; return; }
+    for (uint32_t b = 0; b < nvalid && b < 4; ++b) dst[at + b] = (uint8_t)(v >> (8 * b));
+}
+
+__global__ __launch_bounds__(256) void record_gather_kernel(const char *__restrict__ text, uint64_t n_bytes, uint64_t n_rec,
+                                                            const uint32_t *__restrict__ seq_start, const uint32_t *__restrict__ qual_start,
+                                                            const uint64_t *__restrict__ off, int fastq, int qoff, uint8_t *__restrict__ bases,
+                                                            uint8_t *__restrict__ qual, unsigned int *__restrict__ bad)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t r0 = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+    if (r0 >= n_rec) return;
+    const uint64_t r = r0 + lane;
+    const bool in = r < n_rec;
+    const uint64_t my_o = in ? off[r] : 0;
+    const uint32_t my_len = in ? (uint32_t)(off[r + 1] - my_o) : 0u;
+    const uint32_t my_s = in ? seq_start[r] : 0u, my_q = (in && fastq) ? qual_start[r] : 0u;
+    bool space = false;
+    uint32_t maxlen = my_len;
+    for (int d = 32; d; d >>= 1) maxlen = max(maxlen, (uint32_t)__shfl_xor((int)maxlen, d));
+    const uint32_t lpr = maxlen <= 128 ? 32u : 64u;                 // lanes per record
+    const uint32_t rpi = 64 / lpr;                                  // records per work item
+    const uint32_t chunks = (maxlen + 4 * lpr - 1) / (4 * lpr);     // 4*lpr-byte chunks per record
+    const uint32_t items = (64 / rpi) * chunks;
+    const uint32_t sub = lane & (lpr - 1), which = lane / lpr;
+    for (uint32_t t0 = 0; t0 < items; t0 += 4) {
+        uint32_t c[4], d[4], nv[4];
+        uint64_t dst[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t t = t0 + u, k = min((t / chunks) * rpi + which, 63u), i = ((t % chunks) * lpr + sub) * 4;
+            const uint64_t o = __shfl(my_o, (int)k);
+            const uint32_t len = __shfl(my_len, (int)k), sk = __shfl(my_s, (int)k), qk = __shfl(my_q, (int)k);
+            nv[u] = (t < items && i < len) ? min(4u, len - i) : 0u;
+            dst[u] = o + i;
+            c[u] = nv[u] ? load4(text, (uint64_t)sk + i, n_bytes) : 0x41414141u;
+            d[u] = (nv[u] && fastq) ? load4(text, (uint64_t)qk + i, n_bytes) : 0x21212121u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!nv[u]) continue;
+            const uint32_t keep = nv[u] >= 4 ? 0xffffffffu : ((1u << (8 * nv[u])) - 1u);
+            // (bytes behind the record -- its newline, the next field -- are not part of it: neutral characters)
+            store4(bases, dst[u], map4((c[u] & keep) | (0x41414141u & ~keep), space), nv[u]);
+            if (fastq) store4(qual, dst[u], sub4((d[u] & keep) | (0x21212121u & ~keep), (uint32_t)qoff, space), nv[u]);
         }
     }
     if (space) atomicOr(bad, 4u);
@@ -275,8 +366,14 @@ int rh_parse_reads(real_hip_ctx *ctx, const char *d_text, uint64_t n_bytes, int 
     // 4. symbols and qualities
     if ((rc = rh_reserve(ctx, ctx->p_bases, total ? total : 1))) return rc;
     if (fastq && (rc = rh_reserve(ctx, ctx->p_qual, total ? total : 1))) return rc;
-    hipLaunchKernelGGL(record_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_text, n, (const uint32_t *)seq_start, (const uint32_t *)qual_start,
-                       (const uint64_t *)ctx->p_off.p, fastq, qoff, (uint8_t *)ctx->p_bases.p, (uint8_t *)ctx->p_qual.p, d_bad);
+    if (((uintptr_t)d_text & 3) == 0)
+        hipLaunchKernelGGL(record_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_text, n_bytes, n,
+                           (const uint32_t *)seq_start, (const uint32_t *)qual_start, (const uint64_t *)ctx->p_off.p, fastq, qoff,
+                           (uint8_t *)ctx->p_bases.p, (uint8_t *)ctx->p_qual.p, d_bad);
+    else
+        hipLaunchKernelGGL(record_gather_bytes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_text, n,
+                           (const uint32_t *)seq_start, (const uint32_t *)qual_start, (const uint64_t *)ctx->p_off.p, fastq, qoff,
+                           (uint8_t *)ctx->p_bases.p, (uint8_t *)ctx->p_qual.p, d_bad);
     RH_HIP(ctx, hipGetLastError());
     RH_HIP(ctx, hipMemcpyAsync(h, d_bad, 16, hipMemcpyDeviceToHost, ctx->stream));
     RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
