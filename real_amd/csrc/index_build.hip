@@ -104,7 +104,8 @@ void rh_choose_tables(real_hip_ctx *ctx, uint64_t n_entries)
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
         const double need = 6.0 * 128.0 * (double)(1ull << rpb) + 12.0 * (double)n_entries + 12.0 * (double)(1ull << rpb);
-        rows = rpb < l && need * 1.08 <= (double)total_b;
+        // (only when the rows are reasonably full: a 200 Mbp genome would take the same 2^(l-4) rows as a 3 Gbp one)
+        rows = rpb < l && (double)n_entries / (double)(1ull << rpb) >= 4.0 && need * 1.08 <= (double)total_b;
     }
     if (auto_pb) {
         if (l <= 32 && big) {
