@@ -95,17 +95,17 @@ void rh_choose_tables(real_hip_ctx *ctx, uint64_t n_entries)
     while ((1ull << (lg + 1)) <= (n_entries ? n_entries : 1)) lg++;
     const bool big = lg >= 27 && want != 1;
     bool rows = want == 3;
-    if (want == 0 && auto_pb && big && l <= 32 && !ctx->no_rows) {
+    if (want == 0 && auto_pb && big && !ctx->no_rows) {
         // bucket rows are the faster layout (one HBM line per lookup) when they fit: 128 B x 2^pb x 6 lists plus the
         // build's transients (the full entry array of one list, the window positions, the bucket starts and overflow scans)
         uint32_t rpb = 1;
         while (rpb < 30 && (double)n_entries / (double)(1ull << rpb) > 11.5) rpb++;
-        if (rpb + 4 < l) rpb = l - 4;
+        if (l <= 32 && rpb + 4 < l) rpb = l - 4;
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
         const double need = 6.0 * 128.0 * (double)(1ull << rpb) + 12.0 * (double)n_entries + 12.0 * (double)(1ull << rpb);
         // (only when the rows are reasonably full: a 200 Mbp genome would take the same 2^(l-4) rows as a 3 Gbp one)
-        rows = rpb < l && (double)n_entries / (double)(1ull << rpb) >= 4.0 && need * 1.08 <= (double)total_b;
+        rows = (l <= 32 ? rpb < l : rpb + 32 <= l) && (double)n_entries / (double)(1ull << rpb) >= 4.0 && need * 1.08 <= (double)total_b;
     }
     if (auto_pb) {
         if (l <= 32 && big) {
@@ -123,12 +123,14 @@ void rh_choose_tables(real_hip_ctx *ctx, uint64_t n_entries)
             if (pb < 8) pb = 8;
         }
     }
-    if (rows && auto_pb && l <= 32) {
-        // bucket rows: about 11 entries per 128-byte row of 20, at most 16 signature values per row
+    if (rows && auto_pb) {
+        // bucket rows: about 11 entries per 128-byte row of 20; 32-bit signatures: at most 16 signature values per row
         pb = 1;
         while (pb < 30 && (double)n_entries / (double)(1ull << pb) > 11.5) pb++;
-        if (pb + 4 < l) pb = l - 4;
-        if (pb + 1 > l) pb = l > 1 ? l - 1 : 1;
+        if (l <= 32) {
+            if (pb + 4 < l) pb = l - 4;
+            if (pb + 1 > l) pb = l > 1 ? l - 1 : 1;
+        } else if (pb + 32 > l) pb = l - 32;
     }
     if (pb > l) pb = l; // a signature has seedl bits (two segments of seedl/4 bases)
     if (pb > 30) pb = 30;
@@ -137,7 +139,7 @@ void rh_choose_tables(real_hip_ctx *ctx, uint64_t n_entries)
     uint32_t pshift, fshift, fbits, pbits;
     rh_index_geometry(l, pb, &pshift, &fshift, &fbits, &pbits);
     if (want == 1) ctx->fine = 0;
-    else if (rows && l <= 32 && l >= pb && l - pb >= 1 && l - pb <= 4) ctx->fine = 3;
+    else if (rows && ((l <= 32 && l >= pb && l - pb >= 1 && l - pb <= 4) || (l > 32 && pb + 32 <= l))) ctx->fine = 3;
     else if (rh_is_fine(l, pb)) ctx->fine = 1;
     else if (pbits == 0 && (want == 2 || (auto_pb && big))) ctx->fine = 2;
     else ctx->fine = 0;
@@ -259,13 +261,14 @@ __global__ void fp_table_kernel(const uint32_t *__restrict__ bkt, const uint2 *_
 //   complex bucket: u64 all ones, u32 first entry in the overflow array, u32 entries, sixteen u8 group counts
 //     (255 = "255 or more": bounds by binary search); its entries live in the overflow array as {key, pos}
 // ---------------------------------------------------------------------------
+// (pbits == 0: wide signatures, the entries hold a 32-bit key; key group = its leading four bits)
 __device__ __forceinline__ void bucket_groups(const uint2 *__restrict__ ent, uint32_t start, uint32_t end, uint32_t pbits, uint32_t gmask,
                                               uint32_t cnt[16])
 {
 #pragma unroll
     for (int g = 0; g < 16; ++g) cnt[g] = 0;
     for (uint32_t j = start; j < end; ++j) {
-        const uint32_t k = (ent[j].x >> pbits) & gmask;
+        const uint32_t k = pbits ? ((ent[j].x >> pbits) & gmask) : (ent[j].x >> 28);
 #pragma unroll
         for (int g = 0; g < 16; ++g) if (k == (uint32_t)g) cnt[g]++;
     }
@@ -282,7 +285,7 @@ __global__ void rows_overflow_kernel(const uint32_t *__restrict__ bkt, const uin
         bool complex_ = c > RH_ROW_CAP;
         if (!complex_ && c > 15) {
             uint32_t cnt[16];
-            bucket_groups(ent, start, end, pbits, (1u << fbits) - 1, cnt);
+            bucket_groups(ent, start, end, pbits, fbits >= 32 ? 15u : (1u << fbits) - 1, cnt);
 #pragma unroll
             for (int g = 0; g < 16; ++g) complex_ = complex_ || cnt[g] > 15;
         }
@@ -302,7 +305,7 @@ __global__ void rows_fill_kernel(const uint32_t *__restrict__ bkt, const uint2 *
 #pragma unroll
     for (int i = 0; i < 32; ++i) w[i] = 0;
     uint32_t cnt[16];
-    bucket_groups(ent, start, end, pbits, (1u << fbits) - 1, cnt);
+    bucket_groups(ent, start, end, pbits, fbits >= 32 ? 15u : (1u << fbits) - 1, cnt);
     if (oc) { // complex
         w[0] = w[1] = 0xffffffffu;
         w[2] = os; w[3] = c;
@@ -316,7 +319,7 @@ __global__ void rows_fill_kernel(const uint32_t *__restrict__ bkt, const uint2 *
         const uint32_t pmask = pbits ? ((1u << pbits) - 1) : 0u;
         for (uint32_t j = 0; j < c; ++j) {
             const uint2 e = ent[start + j];
-            const uint32_t key = (e.x & pmask) >> (pbits - p16);
+            const uint32_t key = pbits ? ((e.x & pmask) >> (pbits - p16)) : rh_fp16(e.x);
             // 6 bytes at byte 8 + 6j: halfwords 4+3j (key), 5+3j (pos low), 6+3j (pos high)
             const uint32_t hw[3] = {key & 0xffffu, e.y & 0xffffu, e.y >> 16};
 #pragma unroll

@@ -725,19 +725,35 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
     const uint32_t bb = a.b_bits;
     const uint32_t gbits = a.ix.fbits, pbits = a.ix.pbits, p16 = pbits < 16 ? pbits : 16;
     const uint32_t pmask = (1u << pbits) - 1;
-    // the four seed segments of the strand in 16-bit fields (seedl <= 32: a segment has at most 16 bits); the
-    // signature of list la is two of them (SignatureConstruction.hpp:62-67), picked with shifts -- an array
-    // indexed by the (uniform, run-time) list number would live in scratch memory
-    uint64_t M;
-    {
+    // The signature of list la is two of the four seed segments (SignatureConstruction.hpp:62-67), picked with shifts
+    // from two words -- an array indexed by the (uniform, run-time) list number would live in scratch memory.
+    // narrow (seedl <= 32): the segments in 16-bit fields of M; bucket = signature >> gbits, key group = its low gbits,
+    //   the row key = the leading 16 bits of the partner signature (list 5-la), filtered by symbol mismatches.
+    // wide (entries hold a 32-bit key, pbits == 0): the segments in 32-bit fields of MA|MB; bucket = the signature's
+    //   leading pb bits, key group = the next four, the row key = a 16-bit fingerprint of the 28 key bits below, compared
+    //   for equality (membership in the equal range is settled on the text).
+    const bool wide = pbits == 0;
+    uint64_t M = 0, MA = 0, MB = 0;
+    if (!wide) {
         const uint32_t mb = (1u << bb) - 1;
         M = ((uint64_t)(uint32_t)(s.shi >> bb) << 48) | ((uint64_t)((uint32_t)s.shi & mb) << 32) | ((uint64_t)(uint32_t)(s.slo >> bb) << 16) |
             (uint64_t)((uint32_t)s.slo & mb);
+    } else {
+        const uint64_t mb = (bb >= 32) ? 0xffffffffull : ((1ull << bb) - 1);
+        MA = ((s.shi >> bb) << 32) | (s.shi & mb);
+        MB = ((s.slo >> bb) << 32) | (s.slo & mb);
     }
-    auto sig_of = [&](int la) { // s0..s5 = segments (0,1),(0,2),(0,3),(1,2),(1,3),(2,3)
+    auto sig_of = [&](int la) { // s0..s5 = segments (0,1),(0,2),(0,3),(1,2),(1,3),(2,3); narrow
         const uint32_t xa = (0x940u >> (2 * la)) & 3u, xc = (0xfb9u >> (2 * la)) & 3u;
         return (((uint32_t)(M >> (48 - 16 * xa)) & 0xffffu) << bb) | ((uint32_t)(M >> (48 - 16 * xc)) & 0xffffu);
     };
+    auto sig_wide = [&](int la) {
+        const uint32_t xa = (0x940u >> (2 * la)) & 3u, xc = (0xfb9u >> (2 * la)) & 3u;
+        const uint64_t sa_ = ((xa < 2 ? MA : MB) >> (32 * (1 - (xa & 1)))) & 0xffffffffull;
+        const uint64_t sc_ = ((xc < 2 ? MA : MB) >> (32 * (1 - (xc & 1)))) & 0xffffffffull;
+        return (sa_ << bb) | sc_;
+    };
+    auto bucket_of = [&](int la) { return wide ? (uint32_t)(sig_wide(la) >> a.ix.pshift) : (sig_of(la) >> gbits); };
     uint32_t qn = 0;
     uint4 va0, va1, va2, va3, va4, va5, va6, va7; // (eight scalars, not an array: the array went through scratch memory)
     uint32_t *bkx = reinterpret_cast<uint32_t *>(stg + BKX_OFF);
@@ -746,7 +762,7 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
     // (a macro, not a lambda taking the array by reference: that sent the eight rows through scratch memory)
 #define ISSUE_ROWS(LA)                                                                                                      \
     do {                                                                                                                    \
-        bkx[(lane & 7) * 8 + (lane >> 3)] = act ? (sig_of(LA) >> gbits) : 0u;                                              \
+        bkx[(lane & 7) * 8 + (lane >> 3)] = act ? bucket_of(LA) : 0u;                                                       \
         __builtin_amdgcn_wave_barrier(); /* LDS operations of a wave execute in order; a fence would also wait for loads */ \
         const uint4 b0_ = *reinterpret_cast<const uint4 *>(bkx + (lane >> 3) * 8);                                          \
         const uint4 b1_ = *reinterpret_cast<const uint4 *>(bkx + (lane >> 3) * 8 + 4);                                      \
@@ -779,8 +795,14 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
         auto row = [&](uint32_t d) { return *reinterpret_cast<const uint32_t *>(rowb + ((((d >> 2) ^ sw) << 4) | ((d & 3) << 2))); };
         uint32_t e_cnt = 0, e_j = 0, e_base = 0;
         bool e_ovf = false;
-        const uint32_t sa = sig_of(la), g = sa & ((1u << gbits) - 1);
-        const uint32_t r = sig_of(5 - la) >> (a.l - pbits); // partner bits of the read: leading pbits of s_b
+        uint32_t g, r; // key group; what an entry's key is compared with (narrow: leading pbits of s_b; wide: the 32-bit key)
+        if (!wide) {
+            g = sig_of(la) & ((1u << gbits) - 1);
+            r = sig_of(5 - la) >> (a.l - pbits);
+        } else {
+            r = (uint32_t)(sig_wide(la) >> a.ix.fshift);
+            g = r >> 28;
+        }
         if (mine) {
             s.cL++;
             const uint32_t h0 = row(0), h1 = row(1);
@@ -814,13 +836,15 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
                     const uint2 *__restrict__ E = a.ix.ent[la];
                     uint32_t x = o0, y = o0 + tot;
                     const uint32_t end = y;
-                    while (x < y) { uint32_t mid = x + ((y - x) >> 1); if ((E[mid].x >> pbits) < g) x = mid + 1; else y = mid; }
+                    const uint32_t gs = wide ? 28u : pbits;
+                    while (x < y) { uint32_t mid = x + ((y - x) >> 1); if ((E[mid].x >> gs) < g) x = mid + 1; else y = mid; }
                     e_base = x; y = end;
-                    while (x < y) { uint32_t mid = x + ((y - x) >> 1); if ((E[mid].x >> pbits) <= g) x = mid + 1; else y = mid; }
+                    while (x < y) { uint32_t mid = x + ((y - x) >> 1); if ((E[mid].x >> gs) <= g) x = mid + 1; else y = mid; }
                     e_cnt = x - e_base;
                 }
             }
-            s.cC += e_cnt; s.cP += e_cnt;
+            if (!wide) s.cC += e_cnt; // (wide: counted when the text confirms the membership)
+            s.cP += e_cnt;
         }
         while (true) {
             while (e_j < e_cnt && qn < MQR) {
@@ -832,12 +856,12 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
                     const uint32_t key = (h & 1) ? (d0 >> 16) : (d0 & 0xffffu);
                     pos = (h & 1) ? d1 : ((d0 >> 16) | (d1 << 16));
                     const uint32_t x = key ^ (r >> (pbits - p16));
-                    pass = __popc(((x >> 1) | x) & 0x5555u) <= a.seedkmax;
+                    pass = wide ? (key == rh_fp16(r)) : (__popc(((x >> 1) | x) & 0x5555u) <= a.seedkmax);
                 } else {
                     const uint2 e = a.ix.ent[la][e_base + e_j];
                     pos = e.y;
                     const uint32_t x = (e.x & pmask) ^ r;
-                    pass = __popc(((x >> 1) | x) & 0x55555555u) <= a.seedkmax;
+                    pass = wide ? (e.x == r) : (__popc(((x >> 1) | x) & 0x55555555u) <= a.seedkmax);
                 }
                 // seed popcount filter (match.hpp:386) on the partner symbols the entry carries: more than seedkmax
                 // known mismatches => rejected without touching the text (exact: the full count can only be larger)

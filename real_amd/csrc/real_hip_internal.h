@@ -54,6 +54,9 @@ static inline bool rh_is_fine(uint32_t l, uint32_t pb) { return l >= pb && l - p
 #define RH_ROW_CAP 20u /* entries a bucket row holds (table kind 3) */
 #define RH_FP_SLOTS 8u
 static inline __host__ __device__ uint32_t rh_fp11(uint32_t key) { return (key * 0x9E3779B1u) >> 21; }
+// bucket rows of wide signatures (entries hold a 32-bit key): key group = the key's leading four bits, the row keeps a
+// 16-bit fingerprint of the other 28
+static inline __host__ __device__ uint32_t rh_fp16(uint32_t key) { return ((key & 0x0fffffffu) * 0x9E3779B1u) >> 16; }
 
 // entry geometry shared by the index build and the matcher
 static inline void rh_index_geometry(uint32_t l, uint32_t pb, uint32_t *pshift, uint32_t *fshift, uint32_t *fbits, uint32_t *pbits)

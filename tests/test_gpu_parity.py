@@ -133,6 +133,8 @@ def test_match_all_golden_inputs(ora, path):
     (64, 150, 5, 1, -15), (64, 150, 5, 0, -19), (48, 100, 4, 1, -12), (36, 80, 3, 1, -4),
     # bucket rows (pb + 100): 8 / 16 signature values per row, rows of 6..100 entries (most of them complex at pb 12 / 5)
     (16, 50, 4, 1, 113), (16, 50, 4, 0, 112), (16, 50, 4, 1, 115), (12, 40, 4, 1, 109), (8, 30, 3, 1, 105), (20, 255, 15, 1, 116),
+    # bucket rows of wide signatures (key group = four key bits, 16-bit key fingerprints): rows of 6, 0.4, 50 entries; 32 key bits exactly
+    (64, 150, 5, 1, 115), (64, 150, 5, 0, 119), (48, 100, 4, 1, 112), (36, 80, 3, 1, 104),
 ])
 def test_match_unique_random(ora, seedl, patl, k, scores, pb):
     # (short seeds on a 3 kbp genome: equal ranges of hundreds of entries -> queue refills, saturated groups)
@@ -254,7 +256,8 @@ def test_index_blocks_compose(ora, kind, pb, device_build):
 
 def test_index_layout_device_equals_host(ora):
     g = synth.random_genome(50_000, seed=77, n_frag=3, n_runs=10, repeats=10)
-    for seedl, kw in ((32, {}), (64, {}), (12, {}), (16, dict(table_kind=3, prefix_bits=12)), (16, dict(table_kind=3))):
+    for seedl, kw in ((32, {}), (64, {}), (12, {}), (16, dict(table_kind=3, prefix_bits=12)), (16, dict(table_kind=3)),
+                      (64, dict(table_kind=3, prefix_bits=13))):
         a = UniqueMatcher(_opts(seedl, 2, 3, 1), **kw)
         a.set_text_symbols(0, g.sym, g.frag_start)
         a.build_index_block()
