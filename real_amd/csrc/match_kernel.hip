@@ -38,7 +38,7 @@
 // the batch.  9.5 KiB hold the 64 reads of a wave up to 151 bases each in one go; with the 8 KiB score table that
 // is 46 KiB per workgroup = three workgroups per CU, which is what the registers allow anyway.
 #define QUEUE_BYTES (MQ * 64u * 5u + 6u * 64u * 4u)
-__host__ __device__ constexpr uint32_t stg_bytes(int W, int TK) { return TK == 3 ? 11008u : (W <= 4 ? QUEUE_BYTES : 9728u); }
+__host__ __device__ constexpr uint32_t stg_bytes(int W, int TK) { return TK >= 3 ? 11008u : (W <= 4 ? QUEUE_BYTES : 9728u); }
 // bucket rows (table kind 3): a queue of MQR slots per lane, then the 64 rows of a list, 128 bytes each
 #define MQR 8u
 #define ROWBUF_OFF (MQR * 64u * 5u)
@@ -713,7 +713,7 @@ __device__ __forceinline__ void wave_lds_sync()
 // -- from the same row -- the entries of their key group, apply the partner filter and queue the survivors
 // with their positions.  The loads of the next list are in flight while this one is decoded.  The queue is
 // drained by every lane for itself, in list order, when one is full and at the end.
-template <int W, bool SCORES, bool ALL, bool DEFER, int LA0, int LA1>
+template <int W, bool SCORES, bool ALL, bool DEFER, bool WIDE, int LA0, int LA1>
 __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL, uint8_t *stg, bool act)
 {
     constexpr int NL = LA1 - LA0;
@@ -732,7 +732,7 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
     // wide (entries hold a 32-bit key, pbits == 0): the segments in 32-bit fields of MA|MB; bucket = the signature's
     //   leading pb bits, key group = the next four, the row key = a 16-bit fingerprint of the 28 key bits below, compared
     //   for equality (membership in the equal range is settled on the text).
-    const bool wide = pbits == 0;
+    constexpr bool wide = WIDE; // (a compile-time property of the kernel instance: as a run-time flag it cost the 32-bit path registers)
     uint64_t M = 0, MA = 0, MB = 0;
     if (!wide) {
         const uint32_t mb = (1u << bb) - 1;
@@ -880,7 +880,7 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
 }
 
 // both strands of one read with bucket rows: every lane of the wave comes along, `act` tells which ones have a read
-template <int W, bool SCORES, bool ALL, bool DEFER>
+template <int W, bool SCORES, bool ALL, bool DEFER, bool WIDE>
 __device__ __forceinline__ void match_read_rows(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL, uint8_t *stg, bool act)
 {
     const uint32_t patl = act ? s.patl : 32u * W;
@@ -907,11 +907,11 @@ __device__ __forceinline__ void match_read_rows(const MatchArgs &a, LaneState<W,
         if (!ALL && !SCORES) {
             // uni0s / uni0r early-out (matchUniqueImplementation.cpp:434-436, 470-472): lists 1..5 of a
             // strand are skipped when list 0 left the record in this strand's state with 0 errors
-            match_lists_rows<W, SCORES, ALL, DEFER, 0, 1>(a, s, sLL, stg, go);
+            match_lists_rows<W, SCORES, ALL, DEFER, WIDE, 0, 1>(a, s, sLL, stg, go);
             const unsigned st = (unsigned)(s.info >> ST_SHIFT), er = (unsigned)(s.info >> ER_SHIFT) & 15;
-            match_lists_rows<W, SCORES, ALL, DEFER, 1, 6>(a, s, sLL, stg, go && !(st == (unsigned)(inv ? ST_REVERSE : ST_STRAIGHT) && er == 0));
+            match_lists_rows<W, SCORES, ALL, DEFER, WIDE, 1, 6>(a, s, sLL, stg, go && !(st == (unsigned)(inv ? ST_REVERSE : ST_STRAIGHT) && er == 0));
         } else {
-            match_lists_rows<W, SCORES, ALL, DEFER, 0, 6>(a, s, sLL, stg, go);
+            match_lists_rows<W, SCORES, ALL, DEFER, WIDE, 0, 6>(a, s, sLL, stg, go);
         }
     }
 }
@@ -962,7 +962,8 @@ __device__ __forceinline__ void match_read(const MatchArgs &a, LaneState<W, SCOR
 // than NPEND locations / PEND_EV events is left untouched and its index appended to a.ovf_list.
 // REPEAT = true: the same matcher with in-place scoring over the reads of a.ovf_list (grid-stride; the list
 // length is read from device memory, no host round trip); a lane fetches the bytes of its read itself.
-// TK = kind of the bucket tables: 0 bucket starts, 1 directory entries (digests / fingerprints), 3 bucket rows
+// TK = kind of the bucket tables: 0 bucket starts, 1 directory entries (digests / fingerprints), 3 bucket rows,
+// 4 bucket rows of signatures wider than 32 bits
 template <int W, bool SCORES, bool ALL, int TK, bool REPEAT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 : 2))) void match_kernel(MatchArgs a)
 {
@@ -1009,8 +1010,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
             s.info = a.info[r];
             if (SCORES) s.iscore = a.score[r];
         }
-        if (TK == 3) // bucket rows: lookups by lane groups, the whole wave comes along
-            match_read_rows<W, SCORES, ALL, DEFER>(a, s, sLL, stg, elig);
+        if (TK >= 3) // bucket rows: lookups by lane groups, the whole wave comes along
+            match_read_rows<W, SCORES, ALL, DEFER, TK == 4>(a, s, sLL, stg, elig);
         else if (elig)
             match_read<W, SCORES, ALL, FINE, DEFER>(a, s, sLL, q_pos, q_la, q_cur);
         const bool ovf = DEFER && elig && s.p_n == PEND_OVF;
@@ -1058,8 +1059,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
                     if (SCORES) s.iscore = a.score[r];
                 }
             }
-            if (TK == 3)
-                match_read_rows<W, SCORES, ALL, DEFER>(a, s, sLL, stg, have);
+            if (TK >= 3)
+                match_read_rows<W, SCORES, ALL, DEFER, TK == 4>(a, s, sLL, stg, have);
             else if (have)
                 match_read<W, SCORES, ALL, FINE, DEFER>(a, s, sLL, q_pos, q_la, q_cur);
             if (!have) continue;
@@ -1113,12 +1114,14 @@ template <int W>
 static void launch_match_w(real_hip_ctx *ctx, const MatchArgs &a, bool all, bool repeat)
 {
     if (repeat) {
-        if (a.ix.fine == 3) launch_repeat_wf<W, 3>(ctx, a, all);
+        if (a.ix.fine == 3 && !a.ix.pbits) launch_repeat_wf<W, 4>(ctx, a, all);
+        else if (a.ix.fine == 3) launch_repeat_wf<W, 3>(ctx, a, all);
         else if (a.ix.fine) launch_repeat_wf<W, 1>(ctx, a, all);
         else launch_repeat_wf<W, 0>(ctx, a, all);
         return;
     }
-    if (a.ix.fine == 3) launch_match_wf<W, 3>(ctx, a, all);
+    if (a.ix.fine == 3 && !a.ix.pbits) launch_match_wf<W, 4>(ctx, a, all);
+    else if (a.ix.fine == 3) launch_match_wf<W, 3>(ctx, a, all);
     else if (a.ix.fine) launch_match_wf<W, 1>(ctx, a, all);
     else launch_match_wf<W, 0>(ctx, a, all);
 }
