@@ -265,18 +265,37 @@ def main():
                                         for i, nm in enumerate(["match_unique", "match_all", "all_sort", "index", "match_repeat"])}}), flush=True)
         return
 
+    # N > 1: the records of step k travel to the root while step k+1 is matched (two alternating record buffers)
+    rg = None
+    bufs = [(info, score)]
+    if world > 1:
+        from real_amd.distributed import RecordGatherer
+        rg = RecordGatherer(n, "cpu" if args.rehearse_on_one_gpu else dev, scores=True, dst=0)
+        bufs.append((torch.zeros_like(info), torch.empty_like(score)))
+    stepno = [0]
+
     def step():
-        info.zero_(); score.fill_(-3.4028234663852886e38)     # uniqueinfo(numpat): state NoMatch, score -FLT_MAX
+        slot = stepno[0] % len(bufs)
+        stepno[0] += 1
+        bi, bs = bufs[slot]
+        if rg is not None:
+            rg.wait(slot)                                       # the gather that last read this buffer
+        bi.zero_(); bs.fill_(-3.4028234663852886e38)           # uniqueinfo(numpat): state NoMatch, score -FLT_MAX
         torch.cuda.current_stream().synchronize()
-        m.match_unique(bases, qual, patl=args.patl, info=info, score=score, n_reads=n)
-        if world > 1:                                          # the one collective: records to the root
+        m.match_unique(bases, qual, patl=args.patl, info=bi, score=bs, n_reads=n)
+        if rg is not None:                                      # the one collective: records to the root
             if args.rehearse_on_one_gpu:
-                gather_records(info.cpu(), score.cpu(), dst=0)
+                rg.start(slot, bi.cpu(), bs.cpu())
             else:
-                gather_records(info, score, dst=0)
+                rg.start(slot, bi, bs)
+
+    def drain():
+        if rg is not None:
+            rg.wait_all()
 
     for _ in range(args.warmup):
         step()
+    drain()
     log("warmup done")
     m.counters(reset=True)
     for k in (rlib.K_MATCH_UNIQUE, rlib.K_MATCH_REPEAT):
@@ -287,6 +306,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()                                                    # every step's records have reached the root
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

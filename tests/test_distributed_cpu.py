@@ -27,7 +27,7 @@ def _worker(rank, world, port, out_path):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import oracle_lib as ora
     from real_amd import synth
-    from real_amd.distributed import gather_records, shard_range
+    from real_amd.distributed import RecordGatherer, gather_records, shard_range
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     g = synth.random_genome(60_000, seed=21, n_frag=2, repeats=10)
     b = synth.sample_reads(g, 1001, 100, 0.02, seed=22)            # odd count: unequal shards
@@ -41,6 +41,15 @@ def _worker(rank, world, port, out_path):
     ti = torch.from_numpy(info.view(np.int64).copy())
     ts = torch.from_numpy(score.copy())
     gi, gs = gather_records(ti, ts, dst=0)
+    # the pipelined form: two steps through alternating buffers, the second one carries the records
+    rg = RecordGatherer(ti.shape[0], "cpu", scores=True)
+    bufs = [(torch.zeros_like(ti), torch.zeros_like(ts)), (ti.clone(), ts.clone())]
+    for k in range(2):
+        rg.wait(k % 2)
+        rg.start(k % 2, *bufs[k])
+    rg.wait_all()
+    if rank == 0:
+        assert torch.equal(rg.info_all, gi) and torch.equal(rg.score_all.view(torch.int32), gs.view(torch.int32))
     if rank == 0:
         full_i, full_s, _ = ora.match_unique(og, ix, p, b.bases, b.qual, b.offsets)
         ok = np.array_equal(gi.numpy().view(np.uint64), full_i) and np.array_equal(gs.numpy().view(np.uint32), full_s.view(np.uint32))
