@@ -130,6 +130,7 @@ def main():
     ap.add_argument("--table-kind", type=int, default=0, help="device bucket tables: 0 auto, 1 starts, 2 directory, 3 bucket rows (real_hip.h)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work the baseline sample is sized for (a bounded sample; 40 covers all 50M reads on 16 threads)")
     ap.add_argument("--mode", choices=["unique", "all", "ingest"], default="unique",
                     help="unique = BASELINE configs[1] (default, what the driver runs); all = configs[2] (matchAll, manual runs)")
     ap.add_argument("--host-buffers", action="store_true",
@@ -176,6 +177,12 @@ def main():
     n = args.reads
     bases, qual, true_pos = gen_reads(torch, sym, n, args.patl, 0.02, 4 + rank, dev)
     log("reads generated")
+    # the CPU port keeps the six lists in host memory ((4 or 8) + 4 bytes per window and list): 144 GB for 3 Gbp with
+    # 32-bit signatures, 216 GB with 64-bit ones -- the latter does not fit the box's 270 GiB with everything else
+    host_index_gb = n_entries * 6 * ((4 if args.seedl <= 32 else 8) + 4) / 1e9
+    if host_index_gb > 180 and not args.no_cpu_baseline:
+        log("cpu baseline skipped: the CPU port's index would take %.0f GB of host memory" % host_index_gb)
+        args.no_cpu_baseline = True
     sym_host = sym.cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     del sym
     torch.cuda.empty_cache()
@@ -361,7 +368,7 @@ def main():
                          "work_per_read": {k: ctr[k] / max(ctr["reads"], 1) for k in ("lookups", "probes", "candidates", "seedpass", "hits", "verified")}},
         }
         if world == 1 and not args.no_cpu_baseline:
-            cb, (idx, oinfo, oscore) = cpu_baseline(torch, m, sym_host, frag, opts, bases, qual, args.patl, n, args.cpu_threads)
+            cb, (idx, oinfo, oscore) = cpu_baseline(torch, m, sym_host, frag, opts, bases, qual, args.patl, n, args.cpu_threads, target_s=args.cpu_seconds)
             # the sample doubles as a full-size parity check: GPU records of the sampled reads == CPU port
             stride, k1 = idx
             gi = info[::stride][:k1].contiguous().cpu().numpy().view(np.uint64)
