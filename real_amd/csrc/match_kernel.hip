@@ -1106,7 +1106,7 @@ template <int W, int FINE>
 static void launch_repeat_wf(real_hip_ctx *ctx, const MatchArgs &a, bool all)
 {
     const uint64_t blocks = (a.b.n_reads + 255) / 256;
-    dim3 grid((unsigned)(blocks < 2048 ? blocks : 2048)), block(256);
+    dim3 grid((unsigned)(blocks < 512 ? blocks : 512)), block(256); // (two workgroups per CU: the hand-over list is short)
     if (all) hipLaunchKernelGGL((match_kernel<W, true, true, FINE, true>), grid, block, 0, ctx->stream, a);
     else     hipLaunchKernelGGL((match_kernel<W, true, false, FINE, true>), grid, block, 0, ctx->stream, a);
 }
