@@ -72,6 +72,26 @@ def test_parse_fastq_equals_generator(crlf, trail):
     m.close()
 
 
+def test_parse_text_end_at_every_alignment():
+    # the last characters of the text are read with care (no load may run past its end): every alignment of the end
+    g = synth.random_genome(20_000, seed=15)
+    b0 = synth.sample_reads(g, 40, 100, 0.02, seed=16)
+    m = UniqueMatcher(_opts())
+    for cut in range(9):
+        b = _Batch()
+        n = len(b0.offsets) - 1
+        keep = np.ones(int(b0.offsets[-1]), dtype=bool)
+        keep[int(b0.offsets[-1]) - cut:] = False                 # the last read loses `cut` bases
+        b.bases, b.qual, b.ids = b0.bases[keep], b0.qual[keep], b0.ids
+        b.offsets = b0.offsets.copy().astype(np.uint64)
+        b.offsets[-1] -= np.uint64(cut)
+        for trail in (True, False):
+            p = m.parse_reads(_fastq(b, trailing_newline=trail), fastq=True, quality_offset=33)
+            _check(m, p, b)
+            assert np.array_equal(m.download(p.qual, int(p.n_symbols), np.uint8), b.qual)
+    m.close()
+
+
 def test_parse_device_text_at_odd_address():
     import torch
     g = synth.random_genome(50_000, seed=13)
