@@ -150,11 +150,11 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.rehearse_on_one_gpu:
         local = 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo" if args.rehearse_on_one_gpu else "nccl")     # nccl = RCCL over xGMI
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
 
     G = int(args.genome_mbp * 1e6)
     opts = RealOptions(seedl=args.seedl, seedkmax=2, totalkmax=args.totalk, scores=bool(args.scores), filter_level=2).normalise()
