@@ -18,6 +18,15 @@
  *
  * Threading: one submitting thread per ctx (calls on one ctx are not
  * re-entrant); distinct ctx (one per GPU) are independent.
+ *
+ * Streams: every ctx owns one non-blocking HIP stream and runs all its copies
+ * and kernels there; it knows nothing about the caller's streams.  Device
+ * memory handed to a call (on_device / text_on_device / sym_on_device inputs
+ * and the in/out records of on_device = 1) must therefore be COMPLETE before
+ * the call -- the producing stream synchronised, or an event of it waited for
+ * with real_hip_wait_event() -- and must not be touched until the call (or,
+ * for the _submit forms, the matching real_hip_wait) has returned.  Results
+ * are complete when the synchronous entry points return.
  */
 #ifndef REAL_HIP_H
 #define REAL_HIP_H
@@ -76,6 +85,13 @@ void real_hip_scoring_table(double similarity, double gc, double trans, double e
 
 int  real_hip_create(real_hip_ctx **out, const real_hip_params *p);
 void real_hip_destroy(real_hip_ctx *ctx);
+/* make the ctx's stream wait for a hipEvent_t the caller recorded on a stream of his own (the asynchronous way to
+ * satisfy the "Streams" contract above); returns at once                                                       */
+int  real_hip_wait_event(real_hip_ctx *ctx, void *hip_event);
+/* -s / -e / -q / -filter_level for the calls that follow, with the resident text and index kept (they depend on
+ * -l only): what constructing another UniqueMatcher / AllMatcher over the same ListSet is to the reference
+ * (matchUniqueImplementation.cpp:348-367, matchAllImplementation.cpp:240-259).                                  */
+int  real_hip_set_match_params(real_hip_ctx *ctx, uint32_t seedkmax, uint32_t totalkmax, uint32_t scores, double filter_mult);
 const char *real_hip_strerror(int status);
 const char *real_hip_last_error(const real_hip_ctx *ctx);
 int  real_hip_abi_version(void);

@@ -206,6 +206,22 @@ extern "C" void real_hip_destroy(real_hip_ctx *c)
     if (!(ctx)) return REAL_HIP_E_INVALID;              \
     RH_HIP((ctx), hipSetDevice((ctx)->device));
 
+extern "C" int real_hip_set_match_params(real_hip_ctx *ctx, uint32_t seedkmax, uint32_t totalkmax, uint32_t scores, double filter_mult)
+{
+    if (!ctx) return REAL_HIP_E_INVALID;
+    if (seedkmax > 2 || totalkmax > 15) return rh_fail(ctx, REAL_HIP_E_INVALID, "seedkmax <= 2, totalkmax <= 15 (RealOptions.cpp:172-180, 449-453)", hipSuccess);
+    ctx->prm.seedkmax = seedkmax; ctx->prm.totalkmax = totalkmax; ctx->prm.scores = scores ? 1u : 0u; ctx->prm.filter_mult = filter_mult;
+    return REAL_HIP_OK;
+}
+
+extern "C" int real_hip_wait_event(real_hip_ctx *ctx, void *hip_event)
+{
+    if (!ctx || !hip_event) return REAL_HIP_E_INVALID;
+    RH_HIP(ctx, hipSetDevice(ctx->device));
+    RH_HIP(ctx, hipStreamWaitEvent(ctx->stream, (hipEvent_t)hip_event, 0));
+    return REAL_HIP_OK;
+}
+
 extern "C" int real_hip_device_memory(real_hip_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes)
 {
     RH_ENTER(ctx);

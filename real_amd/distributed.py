@@ -124,3 +124,52 @@ class RecordGatherer:
             else:
                 self.info_all = self.torch.cat([ri[g, :n] for g, n in enumerate(self.sizes)])
                 self.score_all = self.torch.cat([rs[g, :n] for g, n in enumerate(self.sizes)]) if self.scores else None
+
+
+def gather_hits(hits, hit_offsets, dst: int = 0):
+    """matchAll across ranks: gather the shards' variable-length hit lists to `dst` -- counts first, then payload
+    (SURVEY 8e).  Every rank holds the hits of its own contiguous shard of reads as the library returned them
+    (matchAllImplementation.cpp:451-535 emits the unified hit list of every read of a block; here the block's reads
+    are spread over the ranks):
+
+      hits         int32 tensor [n_hits, 4]: the 16-byte real_hip_hit records viewed as four dwords; dword 0 is the
+                   read index INSIDE the shard
+      hit_offsets  int64 tensor [n_local + 1]: hits[hit_offsets[i] : hit_offsets[i+1]] belong to read i of the shard
+
+    Returns on dst (hits_all [H, 4], offsets_all [R + 1]) with read indices rebased to the whole batch (rank order =
+    read order, as shard_range cuts it) and offsets rebased by the hits of the ranks in front; (None, None) elsewhere.
+    Two collectives carry data: one all_gather of {n_local, n_hits} per rank, then one gather of the payload padded to
+    the longest shard (device tensors with nccl = RCCL over xGMI, CPU tensors with gloo)."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = hits.device
+    n_local, n_hits = int(hit_offsets.shape[0]) - 1, int(hits.shape[0])
+    mine = torch.tensor([n_local, n_hits], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(sizes, mine)                                  # counts first
+    sizes = [(int(s[0].item()), int(s[1].item())) for s in sizes]
+    max_r, max_h = max(s[0] for s in sizes), max(s[1] for s in sizes)
+
+    # payload: hit records, and the per-read hit counts (offsets are rebuilt from them on the root)
+    pay_h = torch.zeros((max(max_h, 1), 4), dtype=torch.int32, device=dev)
+    pay_h[:n_hits] = hits.view(-1, 4)[:n_hits]
+    pay_c = torch.zeros(max(max_r, 1), dtype=torch.int64, device=dev)
+    pay_c[:n_local] = hit_offsets[1:] - hit_offsets[:-1]
+    out_h = [torch.empty_like(pay_h) for _ in range(world)] if rank == dst else None
+    out_c = [torch.empty_like(pay_c) for _ in range(world)] if rank == dst else None
+    dist.gather(pay_h, out_h, dst=dst)
+    dist.gather(pay_c, out_c, dst=dst)
+    if rank != dst:
+        return None, None
+    parts, counts, first = [], [], 0
+    for g, (nr, nh) in enumerate(sizes):
+        h = out_h[g][:nh].clone()
+        h[:, 0] += first                                          # read index inside the shard -> inside the batch
+        parts.append(h)
+        counts.append(out_c[g][:nr])
+        first += nr
+    hits_all = torch.cat(parts) if parts else torch.zeros((0, 4), dtype=torch.int32, device=dev)
+    offsets_all = torch.zeros(first + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(torch.cat(counts), 0, out=offsets_all[1:])
+    return hits_all, offsets_all

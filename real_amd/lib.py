@@ -29,7 +29,7 @@ K_MATCH_UNIQUE, K_MATCH_ALL, K_ALL_SORT, K_INDEX, K_MATCH_REPEAT, K_PARSE = rang
 # every symbol include/real_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "real_hip_scoring_table", "real_hip_create", "real_hip_destroy", "real_hip_strerror",
-    "real_hip_last_error", "real_hip_abi_version", "real_hip_device_memory", "real_hip_set_text", "real_hip_set_text_symbols",
+    "real_hip_last_error", "real_hip_abi_version", "real_hip_set_match_params", "real_hip_wait_event", "real_hip_device_memory", "real_hip_set_text", "real_hip_set_text_symbols",
     "real_hip_set_index_block", "real_hip_build_index_block", "real_hip_index_info",
     "real_hip_index_table_kind", "real_hip_index_download", "real_hip_index_export", "real_hip_match_unique", "real_hip_match_all",
     "real_hip_parse_reads", "real_hip_counters_get", "real_hip_kernel_time", "real_hip_timing_enable",
@@ -97,6 +97,8 @@ def load():
     L.real_hip_strerror.restype = C.c_char_p
     L.real_hip_last_error.argtypes = [vp]
     L.real_hip_last_error.restype = C.c_char_p
+    L.real_hip_set_match_params.argtypes = [vp, u32, u32, u32, C.c_double]
+    L.real_hip_wait_event.argtypes = [vp, vp]
     L.real_hip_device_memory.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     L.real_hip_set_text.argtypes = [vp, u32, vp, vp, u64, vp, u32]
     L.real_hip_set_text_symbols.argtypes = [vp, u32, vp, u64, C.c_int, vp, u32]

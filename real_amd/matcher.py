@@ -160,6 +160,17 @@ class HipMatcher:
         if rc != 0:
             raise RealHipError(rc, self._L.real_hip_last_error(self._h).decode() or self._L.real_hip_strerror(rc).decode())
 
+    def set_match_params(self, seedkmax: Optional[int] = None, totalkmax: Optional[int] = None, scores: Optional[bool] = None,
+                         filter_level: Optional[int] = None):
+        """-s / -e / -q / -filter_level for the calls that follow; the resident text and index stay (they depend on -l only)."""
+        o = self.opts
+        if seedkmax is not None: o.seedkmax = seedkmax
+        if totalkmax is not None: o.totalkmax = totalkmax
+        if scores is not None: o.scores = bool(scores)
+        if filter_level is not None: o.filter_level = filter_level
+        o.normalise()
+        self._check(self._L.real_hip_set_match_params(self._h, o.seedkmax, o.totalkmax, int(bool(o.scores)), o.filter_mult))
+
     # -- text --
     def set_text(self, fileid: int, text2bit: np.ndarray, wildbits: np.ndarray, n_bases: int, frag_start: np.ndarray):
         t = np.ascontiguousarray(text2bit, dtype=np.uint64)
@@ -171,6 +182,7 @@ class HipMatcher:
         """sym: numpy uint8 (host) or a torch uint8 tensor (host or device)."""
         f = np.ascontiguousarray(frag_start, dtype=np.uint64)
         on_device = bool(getattr(sym, "is_cuda", False))
+        self.sync_inputs(sym)
         if isinstance(sym, np.ndarray):
             sym = np.ascontiguousarray(sym, dtype=np.uint8)
         n = int(n_bases if n_bases is not None else sym.shape[0])
@@ -221,6 +233,18 @@ class HipMatcher:
 
     # -- batches --
     @staticmethod
+    def sync_inputs(*arrays):
+        """The library runs on the context's own stream and does not know the caller's: device arrays handed over
+        (inputs AND in/out records) must be complete before the call (include/real_hip.h, "Streams").  For torch
+        tensors that means the producing stream has to drain -- done here, once per device."""
+        seen = set()
+        for a in arrays:
+            if a is not None and getattr(a, "is_cuda", False) and a.device not in seen:
+                import torch
+                torch.cuda.current_stream(a.device).synchronize()
+                seen.add(a.device)
+
+    @staticmethod
     def _batch(bases, qual, offsets, patl: int, n_reads: Optional[int], max_patl: int = 0) -> RealHipBatch:
         b = RealHipBatch()
         b.struct_size = C.sizeof(RealHipBatch)
@@ -245,6 +269,7 @@ class HipMatcher:
         b = self._batch(bases, qual, offsets, patl, n_reads, max_patl)
         if info is None:
             info, score = new_unique_info(int(b.n_reads), self.opts.scores)
+        self.sync_inputs(bases, qual, offsets, info, score)
         self._check(self._L.real_hip_match_unique(self._h, C.byref(b), _ptr(info), _ptr(score)))
         return info, score
 
@@ -276,6 +301,7 @@ class HipMatcher:
         if not on_dev and not isinstance(text, np.ndarray):
             text = np.frombuffer(text, dtype=np.uint8)
         n = int(text.numel()) if on_dev else int(text.shape[0])
+        self.sync_inputs(text)
         out = _lib.RealHipParsed()
         self._check(self._L.real_hip_parse_reads(self._h, _ptr(text), n, int(on_dev), int(bool(fastq)), int(quality_offset), C.byref(out)))
         return out

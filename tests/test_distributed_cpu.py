@@ -50,13 +50,35 @@ def _worker(rank, world, port, out_path):
     rg.wait_all()
     if rank == 0:
         assert torch.equal(rg.info_all, gi) and torch.equal(rg.score_all.view(torch.int32), gs.view(torch.int32))
+    # matchAll: variable-length hit lists, counts first, then payload
+    from real_amd.distributed import gather_hits
+    from real_amd.lib import HIT_DTYPE
+
+    def as_abi(oh, ooff):      # oracle hit records -> the ABI's 16-byte real_hip_hit, read index inside the given batch
+        h = np.zeros(oh.shape[0], dtype=HIT_DTYPE)
+        for f in ("pos", "score", "frag", "k", "inverted"):
+            h[f] = oh[f]
+        h["read"] = np.repeat(np.arange(ooff.shape[0] - 1, dtype=np.uint32), np.diff(ooff.astype(np.int64)))
+        return h
+
+    p2 = ora.make_params(seedl=32, seedkmax=2, totalkmax=2, scores=1, threads=1)
+    oh, ooff, _ = ora.match_all(og, ix, p2, b.bases[int(b.offsets[lo]):int(b.offsets[hi])],
+                                b.qual[int(b.offsets[lo]):int(b.offsets[hi])], off)
+    th = torch.from_numpy(as_abi(oh, ooff).view(np.int32).reshape(-1, 4).copy())
+    to = torch.from_numpy(ooff.astype(np.int64))
+    gh, go = gather_hits(th, to, dst=0)
     if rank == 0:
         full_i, full_s, _ = ora.match_unique(og, ix, p, b.bases, b.qual, b.offsets)
         ok = np.array_equal(gi.numpy().view(np.uint64), full_i) and np.array_equal(gs.numpy().view(np.uint32), full_s.view(np.uint32))
+        fh, foff, _ = ora.match_all(og, ix, p2, b.bases, b.qual, b.offsets)
+        want = as_abi(fh, foff)
+        got = gh.numpy().reshape(-1).view(HIT_DTYPE)
+        ok = ok and np.array_equal(go.numpy(), foff.astype(np.int64)) and got.shape == want.shape and got.tobytes() == want.tobytes()
+        ok = ok and want.shape[0] > b.n_reads // 2 and int(np.diff(foff.astype(np.int64)).max()) > 1      # (the case is not trivial)
         with open(out_path, "w") as f:
             f.write("ok" if ok else "mismatch")
     else:
-        assert gi is None and gs is None
+        assert gi is None and gs is None and gh is None and go is None
     dist.barrier()
     dist.destroy_process_group()
 
@@ -67,3 +89,46 @@ def test_two_rank_gloo_shard_and_gather(tmp_path):
     out = str(tmp_path / "result.txt")
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     assert open(out).read() == "ok"
+
+
+def _bench_json(cmd, timeout=600):
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                  # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_n_starts_n_ranks():
+    """`python bench.py --gpus 2` (no torch.distributed environment) must start two ranks itself: the ranks meet
+    over gloo and count each other (--launch-check makes no GPU call, so this runs on the CPU box)."""
+    j = _bench_json(["--gpus", "2", "--launch-check"])
+    assert j["launch_check"] and j["n_gpus"] == 2 and j["world_size_env"] == 2 and j["requested"] == 2
+    j = _bench_json(["--gpus", "1", "--launch-check"])
+    assert j["n_gpus"] == 1
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True, text=True, env=env, cwd=root)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_rehearsal_through_the_launcher():
+    """the N > 1 bench path end to end through the exact launcher, on a 1-GPU box: both ranks on cuda:0, gather over
+    gloo; matchUnique records and (second run) matchAll hit lists reach the root"""
+    small = ["--gpus", "2", "--rehearse-on-one-gpu", "--genome-mbp", "20", "--reads", "200000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    j = _bench_json(small)
+    assert j["n_gpus"] == 2 and j["config"]["distributed"]["world_size"] == 2 and j["config"]["distributed"]["backend"] == "gloo"
+    assert j["value"] > 0 and 0.5 < j["config"]["uniquely_aligned_frac_rank0"] < 1
+    j = _bench_json(small + ["--mode", "all", "--totalk", "2"])
+    assert j["n_gpus"] == 2 and j["config"]["hits_gathered_on_root_per_step"] > j["config"]["hits_per_step_rank0"] > 0
