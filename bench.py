@@ -425,8 +425,11 @@ def main():
     t0 = time.time()
     n_entries, _ = m.build_index_block()
     t_index = time.time() - t0
-    index_kernel_ms = m.kernel_time(rlib.K_INDEX)[0]
-    log("index built: %d entries, prefix_bits %d, %.1f s wall, %.1f s of kernels" % (n_entries, m.prefix_bits, t_index, index_kernel_ms / 1e3))
+    ibs = m.index_build_stats()
+    index_build = {"wall_s": t_index, "kernel_s": ibs["kernel_ms"] / 1e3, "hipMalloc_s": ibs["alloc_ms"] / 1e3, "hipFree_s": ibs["free_ms"] / 1e3,
+                   "allocated_GB": ibs["alloc_bytes"] / 1e9, "hipMalloc_calls": ibs["alloc_calls"]}
+    log("index built: %d entries, prefix_bits %d, %.1f s wall = %.1f s kernels + %.1f s hipMalloc (%.0f GB) + %.1f s hipFree + rest"
+        % (n_entries, m.prefix_bits, t_index, index_build["kernel_s"], index_build["hipMalloc_s"], index_build["allocated_GB"], index_build["hipFree_s"]))
     n = args.reads
     bases, qual, true_pos, true_inv = gen_reads(torch, sym, n, args.patl, 0.02, 4 + rank, dev, shuffle=args.shuffle_reads)
     log("reads generated")
@@ -505,7 +508,7 @@ def main():
                        "parallelism": "reads sharded x%d, index replicated, one RCCL gather of records" % world,
                        "distributed": dist_info,
                        "uniquely_aligned_frac_rank0": aligned / n, "value_counts": "every read of the batch (aligned_reads_per_s = the uniquely aligned ones)",
-                       "index_build_s": t_index, "index_build_kernel_s": index_kernel_ms / 1e3, "setup_s": t_setup,
+                       "index_build_s": t_index, "index_build": index_build, "setup_s": t_setup,
                        "kernel_source_sha": kernel_source_hash()},
             "roofline": roof,
         }
@@ -606,13 +609,15 @@ def extras(torch, dist, rlib, args, m, opts, cpu, sym, sym_host, frag, bases, qu
         t0 = time.time()
         ne5, _ = m5.build_index_block()
         t_ix5 = time.time() - t0
+        ibs5 = m5.index_build_stats()
         b5, q5, pos5, inv5 = gen_reads(torch, sym, n, 150, 0.02, 12, dev)
         dt, ctr, (ms, ln), (rms, rn), (info5, score5) = timed_unique(torch, dist, m5, rlib, b5, q5, 150, n, K, 1, 1, 0, dev, dev)
         st = (info5 >> 61) & 7
         al = ((st == 1) | (st == 2))
         c5 = {"workload": "matchUnique, %dM synthetic 150 bp reads vs %.0f Mbp genome, seedl 64 (64-bit signatures), k=5, scores on (BASELINE configs[4])" % (n // 1_000_000, args.genome_mbp),
               "ms_per_step": dt / K * 1e3, "reads_per_s": n * K / dt, "uniquely_aligned_frac": float(al.float().mean().item()),
-              "index_build_s": t_ix5, "bucket_tables": TABLE_KINDS[m5.table_kind], "prefix_bits": m5.prefix_bits,
+              "index_build_s": t_ix5, "index_build_kernel_s": ibs5["kernel_ms"] / 1e3, "index_build_hipMalloc_s": ibs5["alloc_ms"] / 1e3,
+              "index_build_hipFree_s": ibs5["free_ms"] / 1e3, "bucket_tables": TABLE_KINDS[m5.table_kind], "prefix_bits": m5.prefix_bits,
               "roofline": roofline_block(ctr, ms, ln, 150, 64, True, "match_kernel<W=5,scores=1,unique,tables=%s>" % TABLE_KINDS[m5.table_kind]),
               "repeat_pass_avg_ms": rms / max(rn, 1)}
         # check on a sample against the oracle's text functions (its 64-bit index does not fit the host beside everything else):

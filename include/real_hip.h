@@ -129,6 +129,16 @@ int real_hip_set_index_block(real_hip_ctx *ctx, uint64_t n_entries,
  * arrays as the host-built form.                                              */
 int real_hip_build_index_block(real_hip_ctx *ctx, uint64_t first_window, uint64_t max_entries,
                                uint64_t *n_entries, int *have_next);
+/* where the wall time of the index builds of this ctx went, accumulated since the last reset: the kernels of the
+ * build (HIP events), hipMalloc and hipFree (host clock; the driver maps and clears every page), the rest is
+ * synchronisation and host code.  The counterpart of the reference's "Sorting fragments..." clock
+ * (ListSetBlockReader.hpp:42-48).                                                                             */
+typedef struct real_hip_build_stats {
+    uint32_t struct_size, reserved;
+    double   wall_ms, kernel_ms, alloc_ms, free_ms;
+    uint64_t alloc_bytes, alloc_calls, free_calls;
+} real_hip_build_stats;
+int real_hip_index_build_stats(real_hip_ctx *ctx, real_hip_build_stats *out, int reset);
 /* introspection (tests, CPU baseline): device layout of list k               */
 int real_hip_index_info(const real_hip_ctx *ctx, uint64_t *n_entries, uint32_t *prefix_bits);
 /* kind of the resident bucket tables: 0 bucket starts, 1 group sizes + partner digests, 2 key fingerprints, 3 bucket rows */

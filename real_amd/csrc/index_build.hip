@@ -373,9 +373,9 @@ int rh_rows_unpack(real_hip_ctx *ctx, int list, uint2 *d_entries, uint32_t *d_st
 {
     const uint64_t nb = 1ull << ctx->pb;
     int rc;
-    DevBuf sizes, offs;
+    ScopedBuf sizes(ctx), offs(ctx);
     if ((rc = rh_reserve(ctx, sizes, (nb + 1) * 4))) return rc;
-    if ((rc = rh_reserve(ctx, offs, (nb + 1) * 4))) { rh_release(sizes); return rc; }
+    if ((rc = rh_reserve(ctx, offs, (nb + 1) * 4))) return rc;
     hipLaunchKernelGGL(rows_sizes_kernel, dim3((unsigned)((nb + 1 + 255) / 256)), dim3(256), 0, ctx->stream, (const uint4 *)ctx->bkt[list].p,
                        nb, (uint32_t *)sizes.p);
     size_t tmp = 0;
@@ -387,82 +387,171 @@ int rh_rows_unpack(real_hip_ctx *ctx, int list, uint2 *d_entries, uint32_t *d_st
                            (const uint2 *)ctx->ent[list].p, nb, (const uint32_t *)offs.p, d_entries);
     if (e == hipSuccess && !rc && d_starts) e = hipMemcpyAsync(d_starts, offs.p, (nb + 1) * 4, hipMemcpyDeviceToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    rh_release(sizes); rh_release(offs);
+    else (void)hipStreamSynchronize(ctx->stream);
     if (rc) return rc;
     if (e != hipSuccess) return rh_fail(ctx, REAL_HIP_E_DEVICE, "rows unpack", e);
     return REAL_HIP_OK;
 }
 
-int rh_index_from_sorted(real_hip_ctx *ctx, int list, const void *d_sign, const uint32_t *d_pos, uint64_t n,
-                         unsigned sig_bytes)
+// ---------------------------------------------------------------------------
+// scratch of one index build: ONE allocation for all six lists.  (hipMalloc / hipFree of tens of gigabytes cost
+// far more than the kernels of the build -- the driver clears and maps every page -- so the transients are laid
+// out once, by offset, and regions whose lifetimes do not overlap share their bytes.)
+//   sorted list    keys_b (n x sig_bytes) + vals_b (n x 4): output of the device sort / destination of the upload
+//   X              during the sort: unsorted keys + rocPRIM's temporary storage; afterwards (bucket rows only): the
+//                  full entry array {key, pos} the rows are cut from
+//   tables         bucket starts; rows: overflow counts and their scan
+// Persistent outputs (rows / overflow entries, or entries / bucket tables) are allocations of their own.
+// ---------------------------------------------------------------------------
+struct BuildScratch {
+    ScopedBuf arena;
+    uint8_t *keys_a = nullptr, *keys_b = nullptr;
+    uint32_t *vals_b = nullptr;
+    void *sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    uint2 *ent = nullptr;
+    uint32_t *bkt = nullptr, *ocnt = nullptr, *ostart = nullptr;
+    void *scan_tmp = nullptr;
+    size_t scan_tmp_bytes = 0;
+    explicit BuildScratch(real_hip_ctx *c) : arena(c) {}
+};
+
+template <typename K>
+static hipError_t sort_pairs(void *tmp, size_t &tmp_bytes, const K *kin, K *kout, const uint32_t *vin, uint32_t *vout, uint64_t n,
+                             uint32_t bits, hipStream_t st)
+{
+    // stable LSD radix sort over the signature bits: equal signatures keep ascending position, as the reference's
+    // ParallelRadixSort (ParallelRadixSort.hpp:160-203) does
+    return rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, (size_t)n, 0u, bits, st);
+}
+
+static int plan_scratch(real_hip_ctx *ctx, BuildScratch &S, uint64_t n, unsigned sig_bytes, bool need_sort)
+{
+    const uint32_t l = ctx->prm.seedl;
+    const size_t nn = n ? n : 1, nb1 = ((size_t)1 << ctx->pb) + 1;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t sort_tmp = 0, scan_tmp = 0;
+    if (need_sort && n) {
+        hipError_t e = sig_bytes == 4 ? sort_pairs<uint32_t>(nullptr, sort_tmp, nullptr, nullptr, nullptr, nullptr, n, l, ctx->stream)
+                                      : sort_pairs<uint64_t>(nullptr, sort_tmp, nullptr, nullptr, nullptr, nullptr, n, l, ctx->stream);
+        if (e != hipSuccess) return rh_fail(ctx, REAL_HIP_E_DEVICE, "radix sort (size query)", e);
+    }
+    const bool rows = ctx->fine == 3;
+    if (rows) {
+        hipError_t e = rocprim::exclusive_scan(nullptr, scan_tmp, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, nb1, rocprim::plus<uint32_t>(), ctx->stream);
+        if (e != hipSuccess) return rh_fail(ctx, REAL_HIP_E_DEVICE, "scan (size query)", e);
+    }
+    const size_t o_keys_b = 0, o_vals_b = o_keys_b + al(nn * sig_bytes), o_x = o_vals_b + al(nn * 4);
+    size_t x = need_sort ? al(nn * sig_bytes) + al(sort_tmp ? sort_tmp : 8) : 0;
+    if (rows && al(nn * sizeof(uint2)) > x) x = al(nn * sizeof(uint2));
+    const size_t o_bkt = o_x + x;
+    const size_t o_ocnt = o_bkt + (ctx->fine ? al(nb1 * 4) : 0);       // (kind 0 keeps the bucket starts: an allocation of their own)
+    const size_t o_ostart = o_ocnt + (rows ? al(nb1 * 4) : 0);
+    const size_t o_scan = o_ostart + (rows ? al(nb1 * 4) : 0);
+    const size_t total = o_scan + al(scan_tmp ? scan_tmp : 8);
+    int rc = rh_reserve(ctx, S.arena, total);
+    if (rc) return rc;
+    uint8_t *base = (uint8_t *)S.arena.p;
+    S.keys_b = base + o_keys_b; S.vals_b = (uint32_t *)(base + o_vals_b);
+    S.keys_a = base + o_x; S.sort_tmp = base + o_x + al(nn * sig_bytes); S.sort_tmp_bytes = sort_tmp;
+    S.ent = rows ? (uint2 *)(base + o_x) : nullptr;
+    S.bkt = ctx->fine ? (uint32_t *)(base + o_bkt) : nullptr;
+    S.ocnt = rows ? (uint32_t *)(base + o_ocnt) : nullptr;
+    S.ostart = rows ? (uint32_t *)(base + o_ostart) : nullptr;
+    S.scan_tmp = base + o_scan; S.scan_tmp_bytes = scan_tmp;
+    return REAL_HIP_OK;
+}
+
+// the device tables of list `list` from its sorted {sign, pos} arrays (in S.keys_b / S.vals_b or anywhere else on the device)
+static int index_from_sorted(real_hip_ctx *ctx, BuildScratch &S, int list, const void *d_sign, const uint32_t *d_pos, uint64_t n,
+                             unsigned sig_bytes)
 {
     const uint32_t l = ctx->prm.seedl, pb = ctx->pb;
     uint32_t pshift, fshift, fbits, pbits;
     rh_index_geometry(l, pb, &pshift, &fshift, &fbits, &pbits);
     const uint32_t nb = 1u << pb;
-    int rc = rh_reserve(ctx, ctx->ent[list], (n ? n : 1) * sizeof(uint2));
-    if (rc) return rc;
-    if (ctx->fine) rh_release(ctx->bkt[list]); // holds a uint4 table / the rows of the previous block
-    rc = rh_reserve(ctx, ctx->bkt[list], ((size_t)nb + 1) * 4);
-    if (rc) return rc;
+    const bool rows = ctx->fine == 3;
+    int rc;
+    // the tables of a previous block / build go first: their bytes are needed
+    rh_release(ctx, ctx->bkt[list]);
+    if (rows || !n) rh_release(ctx, ctx->ent[list]);
     if (!n) {
-        const size_t esz = ctx->fine == 3 ? 128 : (ctx->fine ? 16 : 4);
-        if (ctx->fine && (rc = rh_reserve(ctx, ctx->bkt[list], ((size_t)nb + 1) * esz))) return rc;
+        const size_t esz = rows ? 128 : (ctx->fine ? 16 : 4);
+        if ((rc = rh_reserve(ctx, ctx->bkt[list], ((size_t)nb + 1) * esz))) return rc;
+        if ((rc = rh_reserve(ctx, ctx->ent[list], sizeof(uint2)))) return rc;
         RH_HIP(ctx, hipMemsetAsync(ctx->bkt[list].p, 0, ((size_t)nb + 1) * esz, ctx->stream));
         return REAL_HIP_OK;
     }
+    uint2 *d_ent = S.ent;
+    if (!rows) {
+        if ((rc = rh_reserve(ctx, ctx->ent[list], n * sizeof(uint2)))) return rc;
+        d_ent = (uint2 *)ctx->ent[list].p;
+    }
+    uint32_t *d_bkt = S.bkt;
+    if (!ctx->fine) {
+        if ((rc = rh_reserve(ctx, ctx->bkt[list], ((size_t)nb + 1) * 4))) return rc;
+        d_bkt = (uint32_t *)ctx->bkt[list].p;
+    }
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
     const uint64_t *T = (const uint64_t *)ctx->text.p;
+    rh_time_begin(ctx, ctx->stream, REAL_HIP_K_INDEX);
     if (sig_bytes == 4)
         hipLaunchKernelGGL(entries_kernel<uint32_t>, grid, block, 0, ctx->stream, (const uint32_t *)d_sign, d_pos, n, l, list, T,
-                           pshift, fshift, fbits, pbits, nb, (uint2 *)ctx->ent[list].p, (uint32_t *)ctx->bkt[list].p);
+                           pshift, fshift, fbits, pbits, nb, d_ent, d_bkt);
     else
         hipLaunchKernelGGL(entries_kernel<uint64_t>, grid, block, 0, ctx->stream, (const uint64_t *)d_sign, d_pos, n, l, list, T,
-                           pshift, fshift, fbits, pbits, nb, (uint2 *)ctx->ent[list].p, (uint32_t *)ctx->bkt[list].p);
+                           pshift, fshift, fbits, pbits, nb, d_ent, d_bkt);
     RH_HIP(ctx, hipGetLastError());
-    if (ctx->fine == 3) {
-        // rows: overflow sizes, scan, fill; then the full entry array and the bucket starts are dropped
-        RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        rh_release(ctx->keys_b); rh_release(ctx->vals_b); // (device build: the sorted inputs are in ent now)
-        DevBuf ocnt, ostart, rows, ovf;
-        if ((rc = rh_reserve(ctx, ocnt, ((size_t)nb + 1) * 4))) return rc;
-        if ((rc = rh_reserve(ctx, ostart, ((size_t)nb + 1) * 4))) return rc;
+    if (rows) {
+        // rows: overflow sizes, scan, fill
         const dim3 g1((unsigned)(((uint64_t)nb + 1 + 255) / 256)), b1(256);
-        hipLaunchKernelGGL(rows_overflow_kernel, g1, b1, 0, ctx->stream, (const uint32_t *)ctx->bkt[list].p, (const uint2 *)ctx->ent[list].p,
-                           (uint64_t)nb, pbits, fbits, (uint32_t *)ocnt.p);
-        size_t tmp = 0;
-        RH_HIP(ctx, rocprim::exclusive_scan(nullptr, tmp, (uint32_t *)ocnt.p, (uint32_t *)ostart.p, 0u, (size_t)nb + 1, rocprim::plus<uint32_t>(), ctx->stream));
-        if ((rc = rh_reserve(ctx, ctx->sort_tmp, tmp ? tmp : 8))) return rc;
-        RH_HIP(ctx, rocprim::exclusive_scan(ctx->sort_tmp.p, tmp, (uint32_t *)ocnt.p, (uint32_t *)ostart.p, 0u, (size_t)nb + 1, rocprim::plus<uint32_t>(), ctx->stream));
+        hipLaunchKernelGGL(rows_overflow_kernel, g1, b1, 0, ctx->stream, (const uint32_t *)d_bkt, (const uint2 *)d_ent, (uint64_t)nb, pbits, fbits, S.ocnt);
+        size_t tmp = S.scan_tmp_bytes;
+        RH_HIP(ctx, rocprim::exclusive_scan(S.scan_tmp, tmp, S.ocnt, S.ostart, 0u, (size_t)nb + 1, rocprim::plus<uint32_t>(), ctx->stream));
+        rh_time_end(ctx, ctx->stream);
         uint32_t n_ovf = 0;
-        RH_HIP(ctx, hipMemcpyAsync(&n_ovf, (uint32_t *)ostart.p + nb, 4, hipMemcpyDeviceToHost, ctx->stream));
+        RH_HIP(ctx, hipMemcpyAsync(&n_ovf, S.ostart + nb, 4, hipMemcpyDeviceToHost, ctx->stream));
         RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        rh_release(ocnt);
-        if ((rc = rh_reserve(ctx, rows, (size_t)nb * 128))) return rc;
-        if ((rc = rh_reserve(ctx, ovf, ((size_t)n_ovf + 1) * sizeof(uint2)))) return rc;
-        hipLaunchKernelGGL(rows_fill_kernel, dim3((unsigned)(((uint64_t)nb + 255) / 256)), b1, 0, ctx->stream, (const uint32_t *)ctx->bkt[list].p,
-                           (const uint2 *)ctx->ent[list].p, (uint64_t)nb, pbits, fbits, (const uint32_t *)ostart.p, (uint4 *)rows.p, (uint2 *)ovf.p);
+        if ((rc = rh_reserve(ctx, ctx->bkt[list], (size_t)nb * 128))) return rc;
+        if ((rc = rh_reserve(ctx, ctx->ent[list], ((size_t)n_ovf + 1) * sizeof(uint2)))) return rc;
+        rh_time_begin(ctx, ctx->stream, REAL_HIP_K_INDEX);
+        hipLaunchKernelGGL(rows_fill_kernel, dim3((unsigned)(((uint64_t)nb + 255) / 256)), b1, 0, ctx->stream, (const uint32_t *)d_bkt,
+                           (const uint2 *)d_ent, (uint64_t)nb, pbits, fbits, (const uint32_t *)S.ostart, (uint4 *)ctx->bkt[list].p, (uint2 *)ctx->ent[list].p);
+        rh_time_end(ctx, ctx->stream);
         RH_HIP(ctx, hipGetLastError());
-        RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        rh_release(ostart); rh_release(ctx->bkt[list]); rh_release(ctx->ent[list]);
-        ctx->bkt[list] = rows; ctx->ent[list] = ovf;
         return REAL_HIP_OK;
     }
     if (ctx->fine) {
-        DevBuf fine_tab;
-        if ((rc = rh_reserve(ctx, fine_tab, ((size_t)nb + 1) * sizeof(uint4)))) return rc;
+        if ((rc = rh_reserve(ctx, ctx->bkt[list], ((size_t)nb + 1) * sizeof(uint4)))) return rc;
         if (ctx->fine == 1)
             hipLaunchKernelGGL(fine_table_kernel, dim3((unsigned)(((uint64_t)nb + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
-                               (const uint32_t *)ctx->bkt[list].p, (const uint2 *)ctx->ent[list].p, (uint64_t)nb, pbits, fbits,
-                               (uint4 *)fine_tab.p);
+                               (const uint32_t *)d_bkt, (const uint2 *)d_ent, (uint64_t)nb, pbits, fbits, (uint4 *)ctx->bkt[list].p);
         else
             hipLaunchKernelGGL(fp_table_kernel, dim3((unsigned)(((uint64_t)nb + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
-                               (const uint32_t *)ctx->bkt[list].p, (const uint2 *)ctx->ent[list].p, (uint64_t)nb, (uint4 *)fine_tab.p);
+                               (const uint32_t *)d_bkt, (const uint2 *)d_ent, (uint64_t)nb, (uint4 *)ctx->bkt[list].p);
         RH_HIP(ctx, hipGetLastError());
-        RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        rh_release(ctx->bkt[list]);
-        ctx->bkt[list] = fine_tab;
     }
+    rh_time_end(ctx, ctx->stream);
+    return REAL_HIP_OK;
+}
+
+// host-built form (real_hip_set_index_block): the six sorted lists are uploaded one after the other through the scratch
+int rh_index_from_host_lists(real_hip_ctx *ctx, uint64_t n, const void *const sign[6], const uint32_t *const pos[6], unsigned sig_bytes)
+{
+    const double t0 = rh_now_ms();
+    BuildScratch S(ctx);
+    int rc = plan_scratch(ctx, S, n, sig_bytes, false);
+    if (rc) return rc;
+    for (int k = 0; k < 6; ++k) {
+        if (n) {
+            RH_HIP(ctx, hipMemcpyAsync(S.keys_b, sign[k], n * sig_bytes, hipMemcpyHostToDevice, ctx->stream));
+            RH_HIP(ctx, hipMemcpyAsync(S.vals_b, pos[k], n * 4, hipMemcpyHostToDevice, ctx->stream));
+        }
+        if ((rc = index_from_sorted(ctx, S, k, S.keys_b, S.vals_b, n, sig_bytes))) return rc;
+    }
+    RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    rh_time_resolve(ctx);
+    ctx->build_wall_ms += rh_now_ms() - t0;
     return REAL_HIP_OK;
 }
 
@@ -503,33 +592,24 @@ __global__ void keys_kernel(const uint64_t *__restrict__ T, const uint32_t *__re
 }
 
 template <typename K>
-static int sort_list(real_hip_ctx *ctx, int list, const uint32_t *d_wpos, uint64_t n)
+static int sort_list(real_hip_ctx *ctx, BuildScratch &S, int list, const uint32_t *d_wpos, uint64_t n)
 {
     const uint32_t l = ctx->prm.seedl;
-    int rc;
-    if ((rc = rh_reserve(ctx, ctx->keys_a, (n ? n : 1) * sizeof(K)))) return rc;
-    if ((rc = rh_reserve(ctx, ctx->keys_b, (n ? n : 1) * sizeof(K)))) return rc;
-    if ((rc = rh_reserve(ctx, ctx->vals_b, (n ? n : 1) * 4))) return rc;
     if (n) {
+        rh_time_begin(ctx, ctx->stream, REAL_HIP_K_INDEX);
         hipLaunchKernelGGL(keys_kernel<K>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                           (const uint64_t *)ctx->text.p, d_wpos, n, l, list, (K *)ctx->keys_a.p);
-        size_t tmp = 0;
-        RH_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp, (K *)ctx->keys_a.p, (K *)ctx->keys_b.p, d_wpos,
-                                              (uint32_t *)ctx->vals_b.p, (size_t)n, 0u, l, ctx->stream));
-        if ((rc = rh_reserve(ctx, ctx->sort_tmp, tmp ? tmp : 8))) return rc;
-        // stable LSD radix sort over the l signature bits: equal signatures keep ascending position,
-        // as the reference's ParallelRadixSort (ParallelRadixSort.hpp:160-203) does
-        RH_HIP(ctx, rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp, (K *)ctx->keys_a.p, (K *)ctx->keys_b.p, d_wpos,
-                                              (uint32_t *)ctx->vals_b.p, (size_t)n, 0u, l, ctx->stream));
+                           (const uint64_t *)ctx->text.p, d_wpos, n, l, list, (K *)S.keys_a);
+        size_t tmp = S.sort_tmp_bytes;
+        RH_HIP(ctx, sort_pairs<K>(S.sort_tmp, tmp, (const K *)S.keys_a, (K *)S.keys_b, d_wpos, S.vals_b, n, l, ctx->stream));
+        rh_time_end(ctx, ctx->stream);
     }
-    rh_release(ctx->keys_a); // (hipFree waits for the sort) the unsorted keys are done with: room for this list's tables
-    return rh_index_from_sorted(ctx, list, ctx->keys_b.p, (const uint32_t *)ctx->vals_b.p, n, sizeof(K));
+    return index_from_sorted(ctx, S, list, S.keys_b, S.vals_b, n, sizeof(K));
 }
 
 int rh_index_build_device(real_hip_ctx *ctx, uint64_t first_window, uint64_t max_entries, uint64_t *n_entries,
                           int *have_next)
 {
-    RhTimer tm(ctx, REAL_HIP_K_INDEX);
+    const double t0 = rh_now_ms();
     const uint32_t l = ctx->prm.seedl;
     const uint64_t n = ctx->n_bases;
     const uint64_t nwin_all = (n >= l) ? (n - l + 1) : 0;
@@ -537,35 +617,40 @@ int rh_index_build_device(real_hip_ctx *ctx, uint64_t first_window, uint64_t max
     const uint32_t *d_wpos = nullptr;
     uint64_t cnt = 0;
     int rc;
+    // the tables of the previous block go first: their bytes are needed
+    for (int k = 0; k < 6; ++k) { rh_release(ctx, ctx->ent[k]); rh_release(ctx, ctx->bkt[k]); }
     if (ctx->n_wild == 0) {
         cnt = (first_window < nwin_all) ? (nwin_all - first_window) : 0;
         if (cnt > max_entries) cnt = max_entries;
         if ((rc = rh_reserve(ctx, ctx->vals_a, (cnt ? cnt : 1) * 4))) return rc;
+        rh_time_begin(ctx, ctx->stream, REAL_HIP_K_INDEX);
         if (cnt)
             hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream,
                                (uint32_t *)ctx->vals_a.p, first_window, cnt);
+        rh_time_end(ctx, ctx->stream);
         d_wpos = (const uint32_t *)ctx->vals_a.p;
     } else {
         // flags -> compacted ascending window starts (all blocks), then slice
-        DevBuf flags, sel, dcount;
+        ScopedBuf flags(ctx), sel(ctx), dcount(ctx);
         if ((rc = rh_reserve(ctx, flags, nwin_all ? nwin_all : 1))) return rc;
-        if ((rc = rh_reserve(ctx, ctx->vals_a, (nwin_all ? nwin_all : 1) * 4))) { rh_release(flags); return rc; }
-        if ((rc = rh_reserve(ctx, dcount, 8))) { rh_release(flags); return rc; }
+        if ((rc = rh_reserve(ctx, ctx->vals_a, (nwin_all ? nwin_all : 1) * 4))) return rc;
+        if ((rc = rh_reserve(ctx, dcount, 8))) return rc;
         RH_HIP(ctx, hipMemsetAsync(dcount.p, 0, 8, ctx->stream));
         if (nwin_all) {
-            hipLaunchKernelGGL(window_flags_kernel, dim3((unsigned)((nwin_all + 255) / 256)), dim3(256), 0, ctx->stream,
-                               (const uint64_t *)ctx->wild.p, nwin_all, l, (uint8_t *)flags.p);
             size_t tmp = 0;
             RH_HIP(ctx, rocprim::select(nullptr, tmp, rocprim::counting_iterator<uint32_t>(0), (uint8_t *)flags.p,
                                         (uint32_t *)ctx->vals_a.p, (size_t *)dcount.p, (size_t)nwin_all, ctx->stream));
-            if ((rc = rh_reserve(ctx, sel, tmp ? tmp : 8))) { rh_release(flags); rh_release(dcount); return rc; }
+            if ((rc = rh_reserve(ctx, sel, tmp ? tmp : 8))) return rc;
+            rh_time_begin(ctx, ctx->stream, REAL_HIP_K_INDEX);
+            hipLaunchKernelGGL(window_flags_kernel, dim3((unsigned)((nwin_all + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (const uint64_t *)ctx->wild.p, nwin_all, l, (uint8_t *)flags.p);
             RH_HIP(ctx, rocprim::select(sel.p, tmp, rocprim::counting_iterator<uint32_t>(0), (uint8_t *)flags.p,
                                         (uint32_t *)ctx->vals_a.p, (size_t *)dcount.p, (size_t)nwin_all, ctx->stream));
+            rh_time_end(ctx, ctx->stream);
         }
         size_t hcount = 0;
         RH_HIP(ctx, hipMemcpyAsync(&hcount, dcount.p, 8, hipMemcpyDeviceToHost, ctx->stream));
         RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        rh_release(flags); rh_release(sel); rh_release(dcount);
         total_valid = hcount;
         cnt = (first_window < total_valid) ? (total_valid - first_window) : 0;
         if (cnt > max_entries) cnt = max_entries;
@@ -573,26 +658,29 @@ int rh_index_build_device(real_hip_ctx *ctx, uint64_t first_window, uint64_t max
     }
     ctx->n_entries = cnt;
     rh_choose_tables(ctx, cnt);
-    for (int k = 0; k < 6; ++k) {
-        rc = (l <= 32) ? sort_list<uint32_t>(ctx, k, d_wpos, cnt) : sort_list<uint64_t>(ctx, k, d_wpos, cnt);
-        if (rc == REAL_HIP_E_NOMEM && ctx->fine == 3 && ctx->prm.table_kind == 0 && !ctx->no_rows) {
+    for (int attempt = 0;; ++attempt) {
+        BuildScratch S(ctx);
+        rc = plan_scratch(ctx, S, cnt, l <= 32 ? 4 : 8, true);
+        for (int k = 0; k < 6 && !rc; ++k)
+            rc = (l <= 32) ? sort_list<uint32_t>(ctx, S, k, d_wpos, cnt) : sort_list<uint64_t>(ctx, S, k, d_wpos, cnt);
+        if (!rc) RH_HIP(ctx, hipStreamSynchronize(ctx->stream)); // (before the scratch goes)
+        if (rc == REAL_HIP_E_NOMEM && ctx->fine == 3 && ctx->prm.table_kind == 0 && !ctx->no_rows && attempt == 0) {
             // the rows did not fit after all (memory held by others): once more with directory tables
-            for (int j = 0; j < 6; ++j) { rh_release(ctx->ent[j]); rh_release(ctx->bkt[j]); }
-            rh_release(ctx->keys_a); rh_release(ctx->keys_b); rh_release(ctx->vals_b); rh_release(ctx->sort_tmp);
+            (void)hipStreamSynchronize(ctx->stream);
+            for (int j = 0; j < 6; ++j) { rh_release(ctx, ctx->ent[j]); rh_release(ctx, ctx->bkt[j]); }
             ctx->no_rows = true;
             rh_choose_tables(ctx, cnt);
-            k = -1;
             continue;
         }
-        if (rc) return rc;
+        if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+        break;
     }
-    RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    // the sort workspace is large (4 arrays of n); give it back
-    rh_release(ctx->keys_a); rh_release(ctx->keys_b); rh_release(ctx->vals_a); rh_release(ctx->vals_b);
-    rh_release(ctx->sort_tmp);
+    rh_release(ctx, ctx->vals_a); // 4 bytes per window: give it back
+    rh_time_resolve(ctx);
     ctx->have_index = true;
     if (n_entries) *n_entries = cnt;
     if (have_next) *have_next = (first_window + cnt < total_valid) ? 1 : 0;
+    ctx->build_wall_ms += rh_now_ms() - t0;
     return REAL_HIP_OK;
 }
 
@@ -741,11 +829,11 @@ int rh_index_export(real_hip_ctx *ctx, int list, void *h_sign, uint32_t *h_pos)
     int rc;
     if ((rc = rh_reserve(ctx, ctx->keys_a, n * sb))) return rc;
     if ((rc = rh_reserve(ctx, ctx->vals_a, n * 4))) return rc;
-    DevBuf unpacked; // bucket rows: the entries in list order first
+    ScopedBuf unpacked(ctx); // bucket rows: the entries in list order first
     const uint2 *d_ent = (const uint2 *)ctx->ent[list].p;
     if (ctx->fine == 3) {
         if ((rc = rh_reserve(ctx, unpacked, n * sizeof(uint2)))) return rc;
-        if ((rc = rh_rows_unpack(ctx, list, (uint2 *)unpacked.p, nullptr))) { rh_release(unpacked); return rc; }
+        if ((rc = rh_rows_unpack(ctx, list, (uint2 *)unpacked.p, nullptr))) return rc;
         d_ent = (const uint2 *)unpacked.p;
     }
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
@@ -759,6 +847,5 @@ int rh_index_export(real_hip_ctx *ctx, int list, void *h_sign, uint32_t *h_pos)
     if (h_sign) RH_HIP(ctx, hipMemcpyAsync(h_sign, ctx->keys_a.p, n * sb, hipMemcpyDeviceToHost, ctx->stream));
     if (h_pos) RH_HIP(ctx, hipMemcpyAsync(h_pos, ctx->vals_a.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    rh_release(unpacked);
     return REAL_HIP_OK;
 }

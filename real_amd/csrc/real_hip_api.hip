@@ -2,6 +2,7 @@
 // launches.  No CPU fallback: every entry point either runs the HIP path or fails.
 #include "real_hip_internal.h"
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -25,20 +26,31 @@ int rh_fail(real_hip_ctx *ctx, int status, const char *what, hipError_t e)
     return status;
 }
 
+double rh_now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 int rh_reserve(real_hip_ctx *ctx, DevBuf &b, size_t bytes)
 {
     if (bytes <= b.cap) return REAL_HIP_OK;
-    if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    rh_release(ctx, b);
+    const double t0 = rh_now_ms();
     hipError_t e = hipMalloc(&b.p, bytes);
+    if (ctx) { ctx->alloc_ms += rh_now_ms() - t0; ctx->alloc_calls++; ctx->alloc_bytes += bytes; }
     if (e != hipSuccess) { b.p = nullptr; return rh_fail(ctx, REAL_HIP_E_NOMEM, "hipMalloc", e); }
     b.cap = bytes;
     return REAL_HIP_OK;
 }
-void rh_release(DevBuf &b)
+void rh_release(real_hip_ctx *ctx, DevBuf &b)
 {
-    if (b.p) (void)hipFree(b.p);
+    if (b.p) {
+        const double t0 = rh_now_ms();
+        (void)hipFree(b.p); // (waits for the device to go idle)
+        if (ctx) { ctx->free_ms += rh_now_ms() - t0; ctx->free_calls++; }
+    }
     b.p = nullptr; b.cap = 0;
 }
+void rh_release(DevBuf &b) { rh_release(nullptr, b); }
 
 RhTimer::RhTimer(real_hip_ctx *ctx, int w) : c(ctx), which(w)
 {
@@ -291,15 +303,13 @@ extern "C" int real_hip_set_text_symbols(real_hip_ctx *ctx, uint32_t fileid, con
     if (rc) return rc;
     if ((rc = alloc_text(ctx, n))) return rc;
     const uint8_t *d_sym = sym;
-    DevBuf tmp;
+    ScopedBuf tmp(ctx);
     if (!on_device) {
         if ((rc = rh_reserve(ctx, tmp, n ? n : 1))) return rc;
         RH_HIP(ctx, hipMemcpyAsync(tmp.p, sym, n, hipMemcpyHostToDevice, ctx->stream));
         d_sym = (const uint8_t *)tmp.p;
     }
-    rc = rh_pack_text(ctx, d_sym, n);
-    rh_release(tmp);
-    if (rc) return rc;
+    if ((rc = rh_pack_text(ctx, d_sym, n))) return rc; // (synchronous: tmp may go)
     ctx->have_text = true;
     return REAL_HIP_OK;
 }
@@ -314,22 +324,13 @@ extern "C" int real_hip_set_index_block(real_hip_ctx *ctx, uint64_t n, const voi
     if (!sign || !pos || n > 0xffffffffull) return rh_fail(ctx, REAL_HIP_E_INVALID, "bad index block", hipSuccess);
     const unsigned sb = ctx->prm.seedl <= 32 ? 4 : 8; // real.cpp:219-229
     ctx->have_index = false;
+    for (int k = 0; k < 6; ++k)
+        if (n && (!sign[k] || !pos[k])) return rh_fail(ctx, REAL_HIP_E_INVALID, "null list", hipSuccess);
+    for (int k = 0; k < 6; ++k) { rh_release(ctx, ctx->ent[k]); rh_release(ctx, ctx->bkt[k]); } // the previous block's tables
     ctx->n_entries = n;
     rh_choose_tables(ctx, n);
-    RhTimer tm(ctx, REAL_HIP_K_INDEX);
-    int rc;
-    if ((rc = rh_reserve(ctx, ctx->keys_a, (n ? n : 1) * sb))) return rc;
-    if ((rc = rh_reserve(ctx, ctx->vals_a, (n ? n : 1) * 4))) return rc;
-    for (int k = 0; k < 6; ++k) {
-        if (n && (!sign[k] || !pos[k])) return rh_fail(ctx, REAL_HIP_E_INVALID, "null list", hipSuccess);
-        if (n) {
-            RH_HIP(ctx, hipMemcpyAsync(ctx->keys_a.p, sign[k], n * sb, hipMemcpyHostToDevice, ctx->stream));
-            RH_HIP(ctx, hipMemcpyAsync(ctx->vals_a.p, pos[k], n * 4, hipMemcpyHostToDevice, ctx->stream));
-        }
-        if ((rc = rh_index_from_sorted(ctx, k, ctx->keys_a.p, (const uint32_t *)ctx->vals_a.p, n, sb))) return rc;
-        RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    rh_release(ctx->keys_a); rh_release(ctx->vals_a);
+    int rc = rh_index_from_host_lists(ctx, n, sign, pos, sb);
+    if (rc) return rc;
     ctx->have_index = true;
     return REAL_HIP_OK;
 }
@@ -341,6 +342,19 @@ extern "C" int real_hip_build_index_block(real_hip_ctx *ctx, uint64_t first_wind
     if (!ctx->have_text) return rh_fail(ctx, REAL_HIP_E_STATE, "set the text first", hipSuccess);
     ctx->have_index = false;
     return rh_index_build_device(ctx, first_window, max_entries, n_entries, have_next);
+}
+
+extern "C" int real_hip_index_build_stats(real_hip_ctx *ctx, real_hip_build_stats *out, int reset)
+{
+    if (!ctx || !out || out->struct_size != sizeof(real_hip_build_stats)) return REAL_HIP_E_INVALID;
+    out->wall_ms = ctx->build_wall_ms; out->kernel_ms = ctx->k_ms[REAL_HIP_K_INDEX];
+    out->alloc_ms = ctx->alloc_ms; out->free_ms = ctx->free_ms;
+    out->alloc_bytes = ctx->alloc_bytes; out->alloc_calls = ctx->alloc_calls; out->free_calls = ctx->free_calls;
+    if (reset) {
+        ctx->build_wall_ms = ctx->alloc_ms = ctx->free_ms = 0; ctx->alloc_bytes = ctx->alloc_calls = ctx->free_calls = 0;
+        ctx->k_ms[REAL_HIP_K_INDEX] = 0; ctx->k_n[REAL_HIP_K_INDEX] = 0;
+    }
+    return REAL_HIP_OK;
 }
 
 extern "C" int real_hip_index_info(const real_hip_ctx *ctx, uint64_t *n_entries, uint32_t *prefix_bits)
@@ -366,15 +380,14 @@ extern "C" int real_hip_index_download(real_hip_ctx *ctx, int list, uint32_t *en
     if (list < 0 || list > 5) return rh_fail(ctx, REAL_HIP_E_INVALID, "list", hipSuccess);
     const uint64_t n = ctx->n_entries;
     if (ctx->fine == 3) { // bucket rows: entries and bucket starts by an ordered traversal of the rows
-        DevBuf e, st;
+        ScopedBuf e(ctx), st(ctx);
         int rc;
         if ((rc = rh_reserve(ctx, e, (n ? n : 1) * sizeof(uint2)))) return rc;
-        if ((rc = rh_reserve(ctx, st, (((size_t)1 << ctx->pb) + 1) * 4))) { rh_release(e); return rc; }
+        if ((rc = rh_reserve(ctx, st, (((size_t)1 << ctx->pb) + 1) * 4))) return rc;
         rc = rh_rows_unpack(ctx, list, (uint2 *)e.p, (uint32_t *)st.p);
         hipError_t he = hipSuccess;
         if (!rc && n && entries) he = hipMemcpy(entries, e.p, n * sizeof(uint2), hipMemcpyDeviceToHost);
         if (!rc && he == hipSuccess && bucket) he = hipMemcpy(bucket, st.p, (((size_t)1 << ctx->pb) + 1) * 4, hipMemcpyDeviceToHost);
-        rh_release(e); rh_release(st);
         if (rc) return rc;
         if (he != hipSuccess) return rh_fail(ctx, REAL_HIP_E_DEVICE, "index download", he);
         return REAL_HIP_OK;

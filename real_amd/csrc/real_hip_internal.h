@@ -142,6 +142,10 @@ struct real_hip_ctx {
     // matchAll workspace
     DevBuf raw, raw_count, hit_cnt, big_list, keys_a, keys_b, vals_a, vals_b, sort_tmp, hit_off, s_hits;
 
+    // where the wall time of an index build goes (real_hip_index_build_stats)
+    double   alloc_ms = 0, free_ms = 0, build_wall_ms = 0;
+    uint64_t alloc_bytes = 0, alloc_calls = 0, free_calls = 0;
+
     // timing
     bool timing = true;
     double   k_ms[REAL_HIP_K_COUNT] = {};
@@ -162,6 +166,16 @@ int rh_fail(real_hip_ctx *ctx, int status, const char *what, hipError_t e);
     } while (0)
 int rh_reserve(real_hip_ctx *ctx, DevBuf &b, size_t bytes);
 void rh_release(DevBuf &b);
+void rh_release(real_hip_ctx *ctx, DevBuf &b); // (timed: real_hip_index_build_stats)
+double rh_now_ms();
+// a function-local device buffer: released on every exit path
+struct ScopedBuf : DevBuf {
+    real_hip_ctx *c;
+    explicit ScopedBuf(real_hip_ctx *ctx) : c(ctx) {}
+    ~ScopedBuf() { rh_release(c, *this); }
+    ScopedBuf(const ScopedBuf &) = delete;
+    ScopedBuf &operator=(const ScopedBuf &) = delete;
+};
 
 struct RhTimer { // HIP events on the ctx stream around a group of launches
     real_hip_ctx *c;
@@ -183,8 +197,7 @@ int rh_all_finish(real_hip_ctx *ctx, uint64_t n_raw, uint64_t n_reads, real_hip_
 
 // ---- text + index (index_build.hip) ------------------------------------------
 int rh_pack_text(real_hip_ctx *ctx, const uint8_t *d_sym, uint64_t n);
-int rh_index_from_sorted(real_hip_ctx *ctx, int list, const void *d_sign, const uint32_t *d_pos,
-                         uint64_t n, unsigned sig_bytes);
+int rh_index_from_host_lists(real_hip_ctx *ctx, uint64_t n, const void *const sign[6], const uint32_t *const pos[6], unsigned sig_bytes);
 int rh_index_build_device(real_hip_ctx *ctx, uint64_t first_window, uint64_t max_entries,
                           uint64_t *n_entries, int *have_next);
 void rh_choose_tables(real_hip_ctx *ctx, uint64_t n_entries); // sets ctx->pb and ctx->fine

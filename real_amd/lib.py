@@ -30,7 +30,7 @@ K_MATCH_UNIQUE, K_MATCH_ALL, K_ALL_SORT, K_INDEX, K_MATCH_REPEAT, K_PARSE = rang
 ABI_SYMBOLS = [
     "real_hip_scoring_table", "real_hip_create", "real_hip_destroy", "real_hip_strerror",
     "real_hip_last_error", "real_hip_abi_version", "real_hip_set_match_params", "real_hip_wait_event", "real_hip_device_memory", "real_hip_set_text", "real_hip_set_text_symbols",
-    "real_hip_set_index_block", "real_hip_build_index_block", "real_hip_index_info",
+    "real_hip_set_index_block", "real_hip_build_index_block", "real_hip_index_info", "real_hip_index_build_stats",
     "real_hip_index_table_kind", "real_hip_index_download", "real_hip_index_export", "real_hip_match_unique", "real_hip_match_all",
     "real_hip_parse_reads", "real_hip_counters_get", "real_hip_kernel_time", "real_hip_timing_enable",
 ]
@@ -53,6 +53,12 @@ class RealHipParsed(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("max_patl", C.c_uint32), ("n_reads", C.c_uint64), ("n_symbols", C.c_uint64),
                 ("bases", C.c_void_p), ("qual", C.c_void_p), ("offsets", C.c_void_p),
                 ("id_start", C.c_void_p), ("id_len", C.c_void_p)]
+
+
+class RealHipBuildStats(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("reserved", C.c_uint32), ("wall_ms", C.c_double), ("kernel_ms", C.c_double),
+                ("alloc_ms", C.c_double), ("free_ms", C.c_double), ("alloc_bytes", C.c_uint64), ("alloc_calls", C.c_uint64),
+                ("free_calls", C.c_uint64)]
 
 
 class RealHipCounters(C.Structure):
@@ -104,6 +110,7 @@ def load():
     L.real_hip_set_text_symbols.argtypes = [vp, u32, vp, u64, C.c_int, vp, u32]
     L.real_hip_set_index_block.argtypes = [vp, u64, C.POINTER(vp), C.POINTER(vp)]
     L.real_hip_build_index_block.argtypes = [vp, u64, u64, C.POINTER(u64), C.POINTER(C.c_int)]
+    L.real_hip_index_build_stats.argtypes = [vp, C.POINTER(RealHipBuildStats), C.c_int]
     L.real_hip_index_info.argtypes = [vp, C.POINTER(u64), C.POINTER(u32)]
     L.real_hip_index_table_kind.argtypes = [vp, C.POINTER(u32)]
     L.real_hip_parse_reads.argtypes = [vp, vp, u64, C.c_int, C.c_int, C.c_int, C.POINTER(RealHipParsed)]

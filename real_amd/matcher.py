@@ -207,6 +207,13 @@ class HipMatcher:
         self._refresh_index_info()
         return int(n.value), bool(nxt.value)
 
+    def index_build_stats(self, reset: bool = False) -> dict:
+        """where the wall time of this context's index builds went (real_hip_index_build_stats)"""
+        st = _lib.RealHipBuildStats()
+        st.struct_size = C.sizeof(_lib.RealHipBuildStats)
+        self._check(self._L.real_hip_index_build_stats(self._h, C.byref(st), int(reset)))
+        return {k: (float(getattr(st, k)) if k.endswith("_ms") else int(getattr(st, k))) for k, _ in st._fields_ if k not in ("struct_size", "reserved")}
+
     def _refresh_index_info(self):
         n = C.c_uint64(0)
         pb = C.c_uint32(0)
