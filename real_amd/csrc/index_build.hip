@@ -744,23 +744,85 @@ __global__ void all_rank_kernel(const uint4 *__restrict__ seg, const uint64_t *_
     }
 }
 
-// reads with many hits (repeats): one workgroup per read, same ranking
-__global__ void all_rank_big_kernel(const uint4 *__restrict__ seg, const uint64_t *__restrict__ off, const uint32_t *__restrict__ big_list,
-                                    const unsigned long long *__restrict__ big_count, real_hip_hit *__restrict__ out)
+// reads with many hits (repeats): one workgroup per read.  Up to ALL_HUGE hits the same quadratic ranking; beyond
+// (a read on a low-complexity locus has 10^5 hits) a stable LSD radix sort of the segment by (k, pos) -- ten passes of
+// four bits between the segment and the same range of the raw array, which is free once the records are scattered --
+// and a look at the neighbours for the one tie (k, pos) leaves open: the same position on both strands.
+#define ALL_HUGE 1024u
+__device__ __forceinline__ uint64_t hit_key40(const uint4 &h) { return ((uint64_t)(h.w & 0xffu) << 32) | (uint64_t)h.y; }
+
+__global__ __launch_bounds__(256) void all_rank_big_kernel(uint4 *__restrict__ seg, uint4 *__restrict__ scratch, const uint64_t *__restrict__ off,
+                                                           const uint32_t *__restrict__ big_list, const unsigned long long *__restrict__ big_count,
+                                                           real_hip_hit *__restrict__ out)
 {
+    __shared__ uint32_t hist[16 * 256];
+    __shared__ uint32_t tot[16];
+    const uint32_t t = threadIdx.x;
     const uint64_t nb = *big_count;
     for (uint64_t b = blockIdx.x; b < nb; b += gridDim.x) {
         const uint64_t r = big_list[b], o = off[r];
         const uint32_t c = (uint32_t)(off[r + 1] - o);
-        for (uint32_t i = threadIdx.x; i < c; i += blockDim.x) {
-            const uint4 h = seg[o + i];
-            uint32_t rank = 0;
-            for (uint32_t j = 0; j < c; ++j) {
-                const uint4 g = seg[o + j];
-                rank += (hit_less(g, h) || (j < i && !hit_less(h, g))) ? 1u : 0u;
+        if (c <= ALL_HUGE) {
+            for (uint32_t i = t; i < c; i += blockDim.x) {
+                const uint4 h = seg[o + i];
+                uint32_t rank = 0;
+                for (uint32_t j = 0; j < c; ++j) {
+                    const uint4 g = seg[o + j];
+                    rank += (hit_less(g, h) || (j < i && !hit_less(h, g))) ? 1u : 0u;
+                }
+                out[o + rank] = hit_record(h);
             }
+            continue;
+        }
+        uint4 *A = seg + o, *B = scratch + o;
+        const uint32_t chunk = (c + 255u) / 256u, lo = min(c, t * chunk), hi = min(c, lo + chunk);
+        for (uint32_t pass = 0; pass < 10; ++pass) { // (every thread of the workgroup makes the same trips)
+            const uint32_t sh = 4 * pass;
+            uint32_t cnt[16];
+#pragma unroll
+            for (int d = 0; d < 16; ++d) cnt[d] = 0;
+            for (uint32_t i = lo; i < hi; ++i) {
+                const uint32_t dg = (uint32_t)(hit_key40(A[i]) >> sh) & 15u;
+#pragma unroll
+                for (int d = 0; d < 16; ++d) cnt[d] += (dg == (uint32_t)d) ? 1u : 0u;
+            }
+#pragma unroll
+            for (int d = 0; d < 16; ++d) hist[d * 256 + t] = cnt[d];
+            __syncthreads();
+            if (t < 16) { // exclusive scan of digit t's counts over the threads (= over the chunks, in order: stable)
+                uint32_t run = 0;
+                for (uint32_t j = 0; j < 256; ++j) { const uint32_t v = hist[t * 256 + j]; hist[t * 256 + j] = run; run += v; }
+                tot[t] = run;
+            }
+            __syncthreads();
+            if (t == 0) {
+                uint32_t run = 0;
+                for (int d = 0; d < 16; ++d) { const uint32_t v = tot[d]; tot[d] = run; run += v; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int d = 0; d < 16; ++d) cnt[d] = tot[d] + hist[d * 256 + t];
+            for (uint32_t i = lo; i < hi; ++i) {
+                const uint4 h = A[i];
+                const uint32_t dg = (uint32_t)(hit_key40(h) >> sh) & 15u;
+                uint32_t dst = 0;
+#pragma unroll
+                for (int d = 0; d < 16; ++d) if (dg == (uint32_t)d) dst = cnt[d]++;
+                B[dst] = h;
+            }
+            __threadfence_block();
+            __syncthreads();
+            uint4 *x = A; A = B; B = x;
+        }
+        // (ten passes: the sorted records are in the segment again)
+        for (uint32_t i = t; i < c; i += blockDim.x) {
+            const uint4 h = A[i];
+            uint32_t rank = i;
+            if (i + 1 < c) { const uint4 g = A[i + 1]; if (hit_key40(g) == hit_key40(h) && hit_less(g, h)) rank = i + 1; }
+            if (i > 0) { const uint4 g = A[i - 1]; if (hit_key40(g) == hit_key40(h) && hit_less(h, g)) rank = i - 1; }
             out[o + rank] = hit_record(h);
         }
+        __syncthreads();
     }
 }
 
@@ -799,7 +861,7 @@ int rh_all_finish(real_hip_ctx *ctx, uint64_t n_raw, uint64_t n_reads, real_hip_
                            (const uint64_t *)off, (uint32_t *)ctx->vals_a.p, seg);
         hipLaunchKernelGGL(all_rank_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, ctx->stream, (const uint4 *)seg,
                            (const uint64_t *)off, n_reads, d_out, (uint32_t *)ctx->big_list.p, big_count);
-        hipLaunchKernelGGL(all_rank_big_kernel, dim3(1024), dim3(256), 0, ctx->stream, (const uint4 *)seg, (const uint64_t *)off,
+        hipLaunchKernelGGL(all_rank_big_kernel, dim3(1024), dim3(256), 0, ctx->stream, seg, (uint4 *)ctx->raw.p, (const uint64_t *)off,
                            (const uint32_t *)ctx->big_list.p, (const unsigned long long *)big_count, d_out);
     }
     RH_HIP(ctx, hipGetLastError());

@@ -29,7 +29,7 @@
 // dependent random 8..48-byte read of a 128-byte line of an HBM-resident table: the kernel is bound by
 // the HBM lines it moves (20.7 per read with digest tables, 95 % of the sustainable line rate), not by
 // arithmetic (no MFMA: XOR/popcount and a short FP64 add chain).
-#include "kernel_common.h"
+#include "match_common.h"
 
 #define EB 8  // index entries a lane requests per round trip while enumerating equal ranges
 #define MQ 16 // candidate queue slots per lane (LDS); a full queue is drained and refilled
@@ -48,7 +48,8 @@ static_assert(BKX_OFF + 256u <= stg_bytes(4, 3) && ROWBUF_OFF % 16 == 0 && QUEUE
 #define NPEND 2      // verified locations a lane parks until their scores are computed (flush_pending)
 #define PEND_EV 32   // update() events parked with them
 #define SLOT_NONE 3u
-#define PEND_OVF 0xffu // p_n of a read that needs more slots: matched again by the repeat kernel
+#define PEND_OVF 0xffu // p_n of a read that is handed over to the wave-cooperative matcher (match_wave.hip)
+#define BIG_T 48u      // an equal range / bucket scan longer than this many entries is not walked by one lane: hand-over
 
 template <int W, bool SCORES, bool ALL>
 struct LaneState {
@@ -80,145 +81,6 @@ struct LaneState {
 };
 
 
-// revcomp of a read held as W words of 32 bases: out[i] = 3 - in[patl-1-i] (Pattern.hpp:105-128)
-template <int W>
-__device__ __forceinline__ void revcomp_words(const uint64_t *in, uint64_t *out, uint32_t patl)
-{
-    const uint32_t nw = (patl + 31) >> 5;
-    const uint32_t pad = 64 * nw - 2 * patl; // 0..62
-#pragma unroll
-    for (int j = 0; j < W; ++j) {
-        uint64_t x = 0, y = 0;
-#pragma unroll
-        for (int k = 0; k < W; ++k) { // rev2(in[nw-1-j]), rev2(in[nw-2-j]) with register-static indices
-            if ((uint32_t)k + (uint32_t)j + 1 == nw) x = rev2(in[k]);
-            if ((uint32_t)k + (uint32_t)j + 2 == nw) y = rev2(in[k]);
-        }
-        const uint64_t v = pad ? ((x << pad) | (y >> (64 - pad))) : x;
-        const uint64_t valid = ((uint32_t)j + 1 < nw) ? ~0ull : ((uint32_t)j + 1 == nw ? (~0ull << pad) : 0ull);
-        out[j] = ~v & valid;
-    }
-}
-
-// ---- the bytes of a read (mapped symbols or qualities) -------------------------------------------------
-// staged by the wave into its LDS region (row at byte offset lb; the region has STG_PAD bytes of slack in
-// front and 4 behind, so a dword that straddles either end of the row is a harmless over-read) ...
-struct LdsRow {
-    const uint8_t *stg;
-    uint32_t lb;
-    __device__ __forceinline__ uint32_t dword(int byteoff, uint32_t) const
-    {
-        const uint32_t o = lb + (uint32_t)byteoff;
-        const uint32_t *p = reinterpret_cast<const uint32_t *>(stg + (o & ~3u));
-        return __builtin_amdgcn_alignbyte(p[1], p[0], o & 3u);
-    }
-};
-// ... or read in place, byte by byte and never outside the row (repeat kernel: few reads, scattered)
-struct GlobalRow {
-    const uint8_t *row;
-    __device__ __forceinline__ uint32_t dword(int byteoff, uint32_t patl) const
-    {
-        uint32_t v = 0;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int i = byteoff + b;
-            if (i >= 0 && i < (int)patl) v |= (uint32_t)row[i] << (8 * b);
-        }
-        return v;
-    }
-};
-
-// mapped symbols -> 32 bases per word, MSB first (what Pattern::mapped holds, Pattern.hpp:60-103); false
-// if the read holds a symbol > 3 (matchUniqueImplementation.cpp:376-394)
-template <int W, class Row>
-__device__ __forceinline__ bool pack_read(const Row &row, uint32_t patl, uint64_t *O)
-{
-    bool ok = true;
-#pragma unroll
-    for (int j = 0; j < W; ++j) {
-        uint64_t w = 0;
-#pragma unroll
-        for (int d = 0; d < 8; ++d) {
-            const uint32_t bo = 32u * j + 4u * d;
-            if (bo < patl) {
-                uint32_t x = row.dword((int)bo, patl);
-                const uint32_t rem = patl - bo;
-                if (rem < 4) x &= (1u << (8 * rem)) - 1u;
-                if (x & 0xfcfcfcfcu) ok = false;
-                // bytes b0 b1 b2 b3 (2 bits each) -> b0<<6 | b1<<4 | b2<<2 | b3 in bits 24..31 of the product
-                w |= (uint64_t)(((x & 0x03030303u) * 0x40100401u) >> 24) << (56 - 8 * d);
-            }
-        }
-        O[j] = w;
-    }
-    return ok;
-}
-
-// seed halves (m0|m1), (m2|m3) of read[0..l) and of its reverse complement
-// (SignatureConstruction.hpp:347-410)
-template <int W>
-__device__ __forceinline__ void seed_halves(const uint64_t *O, uint32_t l, uint64_t &shi, uint64_t &slo, uint64_t &rhi, uint64_t &rlo)
-{
-    const uint32_t h = l >> 1; // 2..32 bases
-    const uint64_t hm = (h == 32) ? ~0ull : ((1ull << (2 * h)) - 1);
-    shi = O[0] >> (64 - 2 * h);
-    if (2 * h <= 32) slo = (O[0] >> (64 - 4 * h)) & hm;
-    else slo = ((h == 32) ? O[W > 1 ? 1 : 0] : (((O[0] << (2 * h)) | (O[W > 1 ? 1 : 0] >> (64 - 2 * h))) >> (64 - 2 * h)));
-    rhi = (rev2(slo) >> (64 - 2 * h)) ^ hm; // the revcomp of the second half comes first
-    rlo = (rev2(shi) >> (64 - 2 * h)) ^ hm;
-}
-
-// ComputeScore<...,true>::computeScore, ComputeScore.hpp:50-190: sequential FP64 sum in base order
-// starting at 1.0, cast to float once.  Ow = oriented read, tw = text aligned to the read, qrow = the
-// read's qualities as given (oriented here: base i of the reversed read has quality[patl-1-i],
-// Pattern.hpp:105-128); no qualities => 30 (Pattern.hpp:42-45).
-template <int W, class Row>
-__device__ __forceinline__ float score_location(const double *sLL, const uint64_t *Ow, const uint64_t *tw, uint32_t patl,
-                                                const Row &qrow, bool has_q, uint32_t inv)
-{
-    double raw = 1.0;
-    // 16 bases per step in a real (not unrolled) loop: the adds are one dependent chain, and a fully
-    // unrolled body lets the scheduler hoist every table read in front of it (1 wave per SIMD).  The
-    // per-step operands sit in registers and are rotated down by one slot per step, which keeps all
-    // register indices static.
-    constexpr int NQ = 2 * W;
-    uint32_t th[NQ], oh[NQ];
-#pragma unroll
-    for (int c = 0; c < NQ; ++c) {
-        th[c] = (uint32_t)(tw[c >> 1] >> ((c & 1) ? 0 : 32));
-        oh[c] = (uint32_t)(Ow[c >> 1] >> ((c & 1) ? 0 : 32));
-    }
-    const uint32_t nchunk = (patl + 15) >> 4;
-#pragma unroll 1
-    for (uint32_t c = 0; c < nchunk; ++c) {
-        uint32_t qa[4] = {0x1e1e1e1eu, 0x1e1e1e1eu, 0x1e1e1e1eu, 0x1e1e1e1eu};
-        if (has_q) {
-            if (!inv) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) qa[i] = qrow.dword((int)(16 * c) + 4 * i, patl);
-            } else { // bytes [p-15, p] with p = patl-1-16c, last one first
-                const int p0 = (int)patl - 16 - (int)(16 * c);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) qa[i] = __builtin_bswap32(qrow.dword(p0 + 4 * (3 - i), patl));
-            }
-        }
-        const uint32_t lim = min(16u, patl - 16u * c);
-        const uint32_t tr = th[0], rr = oh[0];
-#pragma unroll
-        for (uint32_t u = 0; u < 16; ++u) {
-            if (u < lim) {
-                const uint32_t ref = (tr >> (30 - 2 * u)) & 3;
-                const uint32_t rb = (rr >> (30 - 2 * u)) & 3;
-                const uint32_t q = (qa[u >> 2] >> (8 * (u & 3))) & 0xff;
-                raw += sLL[((ref << 8) | (rb << 6) | q) & 1023];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i + 1 < NQ; ++i) { th[i] = th[i + 1]; oh[i] = oh[i + 1]; }
-    }
-    return (float)raw;
-}
-
 // the update() call itself: the best/unique fold, or the matchAll append
 template <int W, bool SCORES, bool ALL>
 __device__ __forceinline__ void deliver(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, uint32_t pos, uint32_t meta, float score)
@@ -244,6 +106,7 @@ __device__ __forceinline__ void flush_pending(const MatchArgs &a, LaneState<W, S
     float sc[NPEND] = {1.0f, 1.0f};
 #pragma unroll 1
     for (uint32_t j = 0; j < s.p_n; ++j) {
+        if (!SCORES) break; // ComputeScore<...,false>: 1.0f (ComputeScore.hpp:31-45)
         const uint32_t pos = j ? s.p_pos[1] : s.p_pos[0], meta = j ? s.p_meta[1] : s.p_meta[0];
         const uint32_t inv = (meta >> 8) & 1;
         uint64_t Ow[W], tw[W];
@@ -296,7 +159,7 @@ template <int W, bool SCORES, bool ALL, bool DEFER>
 __device__ __forceinline__ void process_candidate(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL,
                                                   uint32_t rpos, uint32_t lmask)
 {
-    if (SCORES && DEFER && s.p_n == PEND_OVF) return; // handed to the repeat kernel
+    if (s.p_n == PEND_OVF) return; // handed over
     const uint64_t *__restrict__ T = a.t.text;
     const uint32_t bb = a.b_bits;
     const uint64_t mb = (bb >= 64) ? ~0ull : ((1ull << bb) - 1);
@@ -362,18 +225,18 @@ __device__ __forceinline__ void process_candidate(const MatchArgs &a, LaneState<
             }
         }
         if (total > a.totalkmax) return;
-        float sc = 1.0f; // ComputeScore<...,false>, ComputeScore.hpp:31-45
-        if (SCORES && !DEFER)
-            sc = score_location<W>(sLL, s.O, tw, s.patl, GlobalRow{a.b.qual + s.o0}, a.b.qual != nullptr, (uint32_t)s.inv);
+        const float sc = 1.0f; // ComputeScore<...,false>, ComputeScore.hpp:31-45 (scores on: computed by flush_pending)
         s.cok = true; s.ck = total; s.cscore = sc; s.cfrag = frag; s.cslot = SLOT_NONE;
-        if (SCORES && DEFER) { // the score is computed later (flush_pending): park the location
-            if (s.p_n == NPEND) { s.p_n = PEND_OVF; return; } // out of room => the read goes to the repeat kernel
+        if (DEFER) { // the score is computed later (flush_pending): park the location
+            if (s.p_n == NPEND) { s.p_n = PEND_OVF; return; } // out of room => the read is handed over
             const uint32_t meta0 = total | ((uint32_t)s.inv << 8) | (frag << 16);
             if (s.p_n) { s.p_pos[1] = pos; s.p_meta[1] = meta0; }
             else {
                 s.p_pos[0] = pos; s.p_meta[0] = meta0;
+                if (SCORES) {
 #pragma unroll
-                for (int j = 0; j < W; ++j) s.p_tw[j] = tw[j];
+                    for (int j = 0; j < W; ++j) s.p_tw[j] = tw[j];
+                }
             }
             s.cslot = s.p_n++;
             reg = true;
@@ -392,11 +255,11 @@ __device__ __forceinline__ void process_candidate(const MatchArgs &a, LaneState<
     }
     const uint32_t meta = s.ck | ((uint32_t)s.inv << 8) | (s.cfrag << 16);
     const uint32_t ne = __popc(events);
-    if (!(SCORES && DEFER)) {
+    if (!DEFER) {
         for (uint32_t e = 0; e < ne; ++e) deliver<W, SCORES, ALL>(a, s, s.cpos, meta, s.cscore);
         return;
     }
-    // park the events (they all refer to the memo's slot); out of room => the read goes to the repeat kernel
+    // park the events (they all refer to the memo's slot); out of room => the read is handed over
     if (s.p_nev + ne > PEND_EV) { s.p_n = PEND_OVF; return; }
     if (s.cslot) s.p_ev |= ((ne >= 32 ? 0xffffffffu : ((1u << ne) - 1u)) << s.p_nev);
     s.p_nev += ne;
@@ -404,14 +267,11 @@ __device__ __forceinline__ void process_candidate(const MatchArgs &a, LaneState<
 
 // Scan of the buckets of lists [LA0, LA1) of one strand; pushes the entries that survive the key
 // (and partner) comparison into the lane's LDS queue, list-major and in entry order = the reference's
-// candidate order.  FIRST = the normal, only pass: all bucket-table loads are issued together, then
-// the first two entries of every bucket together.  !FIRST = continuation after a full queue was
-// drained (repeat-rich loci only): everything is recomputed from the seed halves and the cursors
-// parked in LDS, so that no scan state has to stay in registers across the drain (occupancy).
-// Returns true if the queue filled up (again).
-template <int W, bool SCORES, bool ALL, bool FINE, int LA0, int LA1, bool FIRST>
-__device__ __forceinline__ bool scan_lists(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, uint32_t *q_pos, uint8_t *q_la,
-                                           uint32_t *q_cur, uint32_t &donemask, uint32_t &qn)
+// candidate order.  All bucket-table loads are issued together, then the first two entries of every bucket
+// together.  A scan longer than BIG_T entries, or more survivors than the queue holds (repeat-rich loci only),
+// hands the read over to the wave-cooperative matcher: no lane walks a long range alone.
+template <int W, bool SCORES, bool ALL, int LA0, int LA1>
+__device__ __forceinline__ void scan_lists(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, uint32_t *q_pos, uint8_t *q_la, uint32_t &qn)
 {
     const uint32_t bb = a.b_bits;
     const uint64_t mb = (bb >= 64) ? ~0ull : ((1ull << bb) - 1);
@@ -440,38 +300,29 @@ __device__ __forceinline__ bool scan_lists(const MatchArgs &a, LaneState<W, SCOR
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
         const uint2 *__restrict__ E = a.ix.ent[LA0 + i];
-        if (FIRST) {
-            e0[i] = (lo[i] < hi[i]) ? E[lo[i]] : make_uint2(0xffffffffu, 0);
-            e1[i] = (lo[i] + 1 < hi[i]) ? E[lo[i] + 1] : make_uint2(0xffffffffu, 0);
-        } else {
-            e0[i] = e1[i] = make_uint2(0, 0);
-        }
+        e0[i] = (lo[i] < hi[i]) ? E[lo[i]] : make_uint2(0xffffffffu, 0);
+        e1[i] = (lo[i] + 1 < hi[i]) ? E[lo[i] + 1] : make_uint2(0xffffffffu, 0);
     }
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-        if (FIRST) {
-            s.cL++;
-            cur[i] = lo[i];
-            if (hi[i] - lo[i] > 16) { // large bucket: lower_bound on the key first
-                const uint2 *__restrict__ E = a.ix.ent[LA0 + i];
-                uint32_t x = lo[i], y = hi[i];
-                while (x < y) {
-                    uint32_t mid = x + ((y - x) >> 1);
-                    s.cP++;
-                    if ((E[mid].x >> pbits) < fp[i]) x = mid + 1; else y = mid;
-                }
-                cur[i] = x;
+        s.cL++;
+        cur[i] = lo[i];
+        if (hi[i] - lo[i] > 16) { // large bucket: lower_bound on the key first
+            const uint2 *__restrict__ E = a.ix.ent[LA0 + i];
+            uint32_t x = lo[i], y = hi[i];
+            while (x < y) {
+                uint32_t mid = x + ((y - x) >> 1);
+                s.cP++;
+                if ((E[mid].x >> pbits) < fp[i]) x = mid + 1; else y = mid;
             }
-        } else {
-            cur[i] = q_cur[i * 64];
+            cur[i] = x;
         }
     }
     // 3. scan in list order, queue the survivors
-    bool again = false;
     qn = 0;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-        if (!again && !(donemask & (1u << i))) {
+        if (s.p_n != PEND_OVF) {
             const uint2 *__restrict__ E = a.ix.ent[LA0 + i];
             const uint32_t f = fp[i], h = hi[i];
             // top pbits of the read's partner signature s_b (the signature of list 5-la)
@@ -479,15 +330,16 @@ __device__ __forceinline__ bool scan_lists(const MatchArgs &a, LaneState<W, SCOR
             const int xb = (lb < 3) ? 0 : (lb < 5) ? 1 : 2, xd = (lb == 0) ? 1 : (lb == 1 || lb == 3) ? 2 : 3;
             const uint32_t rp = pbits ? (uint32_t)(((m[xb] << bb) | m[xd]) >> (a.l - pbits)) : 0u;
             uint32_t j = cur[i];
+            const uint32_t jstop = j + BIG_T;
             while (j < h) {
-                if (qn == MQ) { again = true; break; }
+                if (j == jstop || qn == MQ) { s.p_n = PEND_OVF; break; } // a whole wave walks this one (match_wave.hip)
                 uint2 e;
-                if (FIRST && j == lo[i]) e = e0[i];
-                else if (FIRST && j == lo[i] + 1) e = e1[i];
+                if (j == lo[i]) e = e0[i];
+                else if (j == lo[i] + 1) e = e1[i];
                 else e = E[j];
                 s.cP++;
                 const uint32_t ek = e.x >> pbits;
-                if (ek > f) { j = h; break; }
+                if (ek > f) break;
                 if (ek == f) {
                     bool keep = true;
                     if (pbits) {
@@ -502,15 +354,8 @@ __device__ __forceinline__ bool scan_lists(const MatchArgs &a, LaneState<W, SCOR
                 }
                 j++;
             }
-            cur[i] = j;
-            if (!again) donemask |= 1u << i;
         }
     }
-    if (again) { // park the cursors in LDS; the continuation pass reloads them
-#pragma unroll
-        for (int i = 0; i < NL; ++i) q_cur[i * 64] = cur[i];
-    }
-    return again;
 }
 
 // Fine tables (32-bit signatures, large index): the 16-byte bucket table entry {start, size and partner digest
@@ -614,13 +459,14 @@ __device__ __forceinline__ void match_lists_fine(const MatchArgs &a, LaneState<W
                 if (__popc(((x >> 1) | x) & 0x55u) > a.seedkmax) sz = 0;
             }
             }
+            if (sz > BIG_T) s.p_n = PEND_OVF; // a long equal range is walked by a whole wave (match_wave.hip)
             lo[i] = start; cum[i] = total; total += sz;
             s.cL++;
         }
     }
     s.cC += counted; s.cP += counted;
     // 2. enumerate, filter, queue, drain
-    for (uint32_t kb = 0; kb < total && !(DEFER && s.p_n == PEND_OVF); kb += MQ) {
+    for (uint32_t kb = 0; kb < total && !(s.p_n == PEND_OVF); kb += MQ) {
         const uint32_t kend = min(total, kb + (uint32_t)MQ);
         uint32_t qn = 0;
         for (uint32_t k0 = kb; k0 < kend; k0 += EB) {
@@ -664,19 +510,14 @@ __device__ __forceinline__ void match_lists_fine(const MatchArgs &a, LaneState<W
 // lists [LA0, LA1) of one strand
 template <int W, bool SCORES, bool ALL, bool FINE, bool DEFER, int LA0, int LA1>
 __device__ __forceinline__ void match_lists(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL,
-                                            uint32_t *q_pos, uint8_t *q_la, uint32_t *q_cur)
+                                            uint32_t *q_pos, uint8_t *q_la)
 {
     if (FINE) { match_lists_fine<W, SCORES, ALL, DEFER, LA0, LA1>(a, s, sLL, q_pos, q_la); return; }
-    uint32_t donemask = 0, qn = 0;
-    bool again = scan_lists<W, SCORES, ALL, FINE, LA0, LA1, true>(a, s, q_pos, q_la, q_cur, donemask, qn);
+    uint32_t qn = 0;
+    scan_lists<W, SCORES, ALL, LA0, LA1>(a, s, q_pos, q_la, qn);
     // 4. verify / score / fold in candidate order
-    for (uint32_t k = 0; k < qn; ++k)
+    for (uint32_t k = 0; k < qn && s.p_n != PEND_OVF; ++k)
         process_candidate<W, SCORES, ALL, DEFER>(a, s, sLL, q_pos[k * 64], (uint32_t)q_la[k * 64]);
-    while (again) {
-        again = scan_lists<W, SCORES, ALL, FINE, LA0, LA1, false>(a, s, q_pos, q_la, q_cur, donemask, qn);
-        for (uint32_t k = 0; k < qn; ++k)
-            process_candidate<W, SCORES, ALL, DEFER>(a, s, sLL, q_pos[k * 64], (uint32_t)q_la[k * 64]);
-    }
 }
 
 // the wave copies bytes [src, src+nbytes) of the batch into its LDS region with 16-byte loads that are
@@ -789,7 +630,7 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
         wave_lds_sync();
         if (li + 1 < NL) ISSUE_ROWS(la + 1); // the next list's rows are in flight while this one is decoded and drained
         // owners: directory of the row, then the entries of their key group
-        const bool mine = act && !(DEFER && s.p_n == PEND_OVF);
+        const bool mine = act && !(s.p_n == PEND_OVF);
         const uint8_t *rowb = rowbuf + lane * 128;
         const uint32_t sw = lane & 7;
         auto row = [&](uint32_t d) { return *reinterpret_cast<const uint32_t *>(rowb + ((((d >> 2) ^ sw) << 4) | ((d & 3) << 2))); };
@@ -845,6 +686,7 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
             }
             if (!wide) s.cC += e_cnt; // (wide: counted when the text confirms the membership)
             s.cP += e_cnt;
+            if (e_cnt > BIG_T) { s.p_n = PEND_OVF; e_cnt = 0; } // a long equal range is walked by a whole wave (match_wave.hip)
         }
         while (true) {
             while (e_j < e_cnt && qn < MQR) {
@@ -873,7 +715,7 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
             for (uint32_t k = 0; k < qn; ++k)
                 process_candidate<W, SCORES, ALL, DEFER>(a, s, sLL, q_pos[k * 64], (uint32_t)q_la[k * 64]);
             qn = 0;
-            if (DEFER && s.p_n == PEND_OVF) e_j = e_cnt;
+            if (s.p_n == PEND_OVF) e_j = e_cnt;
             if (!__any(e_j < e_cnt)) break;
         }
     }
@@ -903,7 +745,7 @@ __device__ __forceinline__ void match_read_rows(const MatchArgs &a, LaneState<W,
         s.so = inv ? (patl - a.l) : 0u; // RestMatch::getMatchOffset, RestMatch.hpp:84-89
         s.cpos = 0xffffffffu; s.ck = 0; s.cfrag = 0; s.cscore = 1.0f; s.cok = false;
         s.crpos = 0xffffffffu; s.ckk = 0;
-        const bool go = act && !(DEFER && s.p_n == PEND_OVF);
+        const bool go = act && !(s.p_n == PEND_OVF);
         if (!ALL && !SCORES) {
             // uni0s / uni0r early-out (matchUniqueImplementation.cpp:434-436, 470-472): lists 1..5 of a
             // strand are skipped when list 0 left the record in this strand's state with 0 errors
@@ -920,7 +762,7 @@ __device__ __forceinline__ void match_read_rows(const MatchArgs &a, LaneState<W,
 // matchAllImplementation.cpp:261-355): s.O holds the read as given on entry, its reverse complement on exit
 template <int W, bool SCORES, bool ALL, bool FINE, bool DEFER>
 __device__ __forceinline__ void match_read(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL, uint32_t *q_pos,
-                                           uint8_t *q_la, uint32_t *q_cur)
+                                           uint8_t *q_la)
 {
     const uint32_t patl = s.patl;
     s.nw = (patl + 31) >> 5;
@@ -930,7 +772,7 @@ __device__ __forceinline__ void match_read(const MatchArgs &a, LaneState<W, SCOR
     uint64_t rhi, rlo;
     seed_halves<W>(s.O, a.l, s.shi, s.slo, rhi, rlo);
     for (int inv = 0; inv < 2; ++inv) {
-        if (DEFER && s.p_n == PEND_OVF) break;
+        if (s.p_n == PEND_OVF) break;
         if (inv) { // transposed pattern, Pattern.hpp:105-128
             uint64_t R[W];
             revcomp_words<W>(s.O, R, patl);
@@ -945,30 +787,29 @@ __device__ __forceinline__ void match_read(const MatchArgs &a, LaneState<W, SCOR
         if (!ALL && !SCORES) {
             // uni0s / uni0r early-out (matchUniqueImplementation.cpp:434-436, 470-472): lists 1..5 of a
             // strand are skipped when list 0 left the record in this strand's state with 0 errors
-            match_lists<W, SCORES, ALL, FINE, DEFER, 0, 1>(a, s, sLL, q_pos, q_la, q_cur);
+            match_lists<W, SCORES, ALL, FINE, DEFER, 0, 1>(a, s, sLL, q_pos, q_la);
             const unsigned st = (unsigned)(s.info >> ST_SHIFT), er = (unsigned)(s.info >> ER_SHIFT) & 15;
             if (!(st == (unsigned)(inv ? ST_REVERSE : ST_STRAIGHT) && er == 0))
-                match_lists<W, SCORES, ALL, FINE, DEFER, 1, 6>(a, s, sLL, q_pos, q_la, q_cur);
+                match_lists<W, SCORES, ALL, FINE, DEFER, 1, 6>(a, s, sLL, q_pos, q_la);
         } else {
-            match_lists<W, SCORES, ALL, FINE, DEFER, 0, 6>(a, s, sLL, q_pos, q_la, q_cur);
+            match_lists<W, SCORES, ALL, FINE, DEFER, 0, 6>(a, s, sLL, q_pos, q_la);
         }
     }
 }
 
-// REPEAT = false: the matcher proper, lane i of the grid takes read i of the batch.  A wave reads the bases
-// of its 64 reads -- one contiguous byte range of the caller's array -- through LDS, every lane packs its
-// own read into registers, matches both strands, and parks its hits (DEFER, scores on); then the wave reads
-// the qualities of its reads the same way and the lanes score and deliver together.  A read that needs more
-// than NPEND locations / PEND_EV events is left untouched and its index appended to a.ovf_list.
-// REPEAT = true: the same matcher with in-place scoring over the reads of a.ovf_list (grid-stride; the list
-// length is read from device memory, no host round trip); a lane fetches the bytes of its read itself.
+// The matcher proper: lane i of the grid takes read i of the batch.  A wave reads the bases of its 64 reads -- one
+// contiguous byte range of the caller's array -- through LDS, every lane packs its own read into registers, matches
+// both strands, and parks its hits (DEFER: scores on, or matchAll); then the wave reads the qualities of its reads the
+// same way and the lanes score and deliver together.  A read that needs more than NPEND locations / PEND_EV events,
+// or meets an equal range of more than BIG_T entries, is left untouched and its index appended to a.ovf_list: the
+// wave-cooperative matcher (match_wave.hip) does it all and counts it.
 // TK = kind of the bucket tables: 0 bucket starts, 1 directory entries (digests / fingerprints), 3 bucket rows,
 // 4 bucket rows of signatures wider than 32 bits
-template <int W, bool SCORES, bool ALL, int TK, bool REPEAT>
+template <int W, bool SCORES, bool ALL, int TK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 : 2))) void match_kernel(MatchArgs a)
 {
     constexpr bool FINE = TK != 0;
-    constexpr bool DEFER = SCORES && !REPEAT;
+    constexpr bool DEFER = SCORES || ALL;
     __shared__ double sLL[SCORES ? 1024 : 1];
     __shared__ __attribute__((aligned(16))) uint8_t smem[4 * stg_bytes(W, TK)];
     if (SCORES) {
@@ -979,100 +820,74 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
     uint8_t *stg = smem + (threadIdx.x >> 6) * stg_bytes(W, TK);
     uint32_t *q_pos = reinterpret_cast<uint32_t *>(stg) + lane;
     uint8_t *q_la = stg + MQ * 64 * 4 + lane;
-    uint32_t *q_cur = reinterpret_cast<uint32_t *>(stg + MQ * 64 * 5) + lane;
     LaneState<W, SCORES, ALL> s;
     s.cL = s.cP = s.cC = s.cS = s.cH = s.cV = 0;
     s.info = 0; s.iscore = 0.f; s.o0 = 0;
     unsigned cR = 0;
     const uint64_t n = a.b.n_reads;
 
-    if (!REPEAT) {
-        const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-        const uint64_t rc = r < n ? r : n; // lanes behind the batch: an empty range at its end
-        const uint64_t o0 = a.b.off ? a.b.off[rc] : rc * (uint64_t)a.b.upatl;
-        const uint64_t o1 = r < n ? (a.b.off ? a.b.off[r + 1] : o0 + a.b.upatl) : o0;
-        const uint32_t patl = (uint32_t)(o1 - o0);
-        const uint32_t GL = a.b.gl; // reads the wave stages at a time: GL * max_patl fits its LDS region
-        // ---- bases: global -> LDS -> registers
-        bool elig = false;
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t rc = r < n ? r : n; // lanes behind the batch: an empty range at its end
+    const uint64_t o0 = a.b.off ? a.b.off[rc] : rc * (uint64_t)a.b.upatl;
+    const uint64_t o1 = r < n ? (a.b.off ? a.b.off[r + 1] : o0 + a.b.upatl) : o0;
+    const uint32_t patl = (uint32_t)(o1 - o0);
+    const uint32_t GL = a.b.gl; // reads the wave stages at a time: GL * max_patl fits its LDS region
+    const uint32_t stg_cap = stg_bytes(W, TK) - STG_PAD - 32u; // bytes of a group the region holds (skew, pad, over-read)
+    // ---- bases: global -> LDS -> registers
+    bool elig = false, toolong = false;
+    for (uint32_t g = 0; g < 64; g += GL) {
+        const uint64_t gb = __shfl(o0, (int)g), ge = __shfl(o1, (int)(g + GL - 1));
+        // (offsets that are not monotone, or reads longer than the declared bound: nothing is staged past the region)
+        const bool fits = ge >= gb && ge - gb <= stg_cap;
+        wave_lds_sync();
+        uint32_t l0 = 0;
+        if (fits) l0 = stage_wave(stg, a.b.bases + gb, ge - gb, lane);
+        wave_lds_sync();
+        const bool in_group = lane >= g && lane < g + GL && r < n;
+        if (in_group && (!fits || o1 < o0 || patl > 32u * W)) toolong = true;
+        if (in_group && fits && o1 >= o0 && patl >= a.l && patl <= 32u * W) // matchUniqueImplementation.cpp:376-394
+            elig = pack_read<W>(LdsRow{stg, l0 + (uint32_t)(o0 - gb)}, patl, s.O);
+    }
+    if (toolong) atomicOr(a.err_flags, 1u); // the host turns this into REAL_HIP_E_INVALID / E_UNSUPPORTED
+    wave_lds_sync();
+    // ---- match
+    s.r = r; s.patl = patl; s.p_n = 0; s.nhit = 0;
+    if (elig && !ALL) {
+        s.info = a.info[r];
+        if (SCORES) s.iscore = a.score[r];
+    }
+    if (TK >= 3) // bucket rows: lookups by lane groups, the whole wave comes along
+        match_read_rows<W, SCORES, ALL, DEFER, TK == 4>(a, s, sLL, stg, elig);
+    else if (elig)
+        match_read<W, SCORES, ALL, FINE, DEFER>(a, s, sLL, q_pos, q_la);
+    const bool ovf = elig && s.p_n == PEND_OVF;
+    if (ovf) {
+        // nothing of this read has been delivered: the wave-cooperative matcher does it all and counts it
+        const unsigned long long slot = wave_append_slot(a.ovf_count);
+        a.ovf_list[slot] = (uint32_t)r;
+        s.cL = s.cP = s.cC = s.cS = s.cH = s.cV = 0;
+    }
+    // ---- qualities: global -> LDS; score the parked hits and deliver them
+    if (DEFER) {
         for (uint32_t g = 0; g < 64; g += GL) {
             const uint64_t gb = __shfl(o0, (int)g), ge = __shfl(o1, (int)(g + GL - 1));
+            const bool mine = lane >= g && lane < g + GL && elig && !ovf && s.p_n;
+            if (!__any(mine)) continue;
+            uint32_t l0 = 0;
             wave_lds_sync();
-            const uint32_t l0 = stage_wave(stg, a.b.bases + gb, ge - gb, lane);
+            if (SCORES && a.b.qual) l0 = stage_wave(stg, a.b.qual + gb, ge - gb, lane); // (fits: the bases of this group did)
             wave_lds_sync();
-            if (lane >= g && lane < g + GL && patl >= a.l && patl <= 32u * W) // matchUniqueImplementation.cpp:376-394
-                elig = pack_read<W>(LdsRow{stg, l0 + (uint32_t)(o0 - gb)}, patl, s.O);
-        }
-        wave_lds_sync();
-        // ---- match
-        s.r = r; s.patl = patl; s.p_n = 0; s.nhit = 0;
-        if (elig && !ALL) {
-            s.info = a.info[r];
-            if (SCORES) s.iscore = a.score[r];
-        }
-        if (TK >= 3) // bucket rows: lookups by lane groups, the whole wave comes along
-            match_read_rows<W, SCORES, ALL, DEFER, TK == 4>(a, s, sLL, stg, elig);
-        else if (elig)
-            match_read<W, SCORES, ALL, FINE, DEFER>(a, s, sLL, q_pos, q_la, q_cur);
-        const bool ovf = DEFER && elig && s.p_n == PEND_OVF;
-        if (ovf) {
-            // nothing of this read has been delivered: the repeat kernel does it all and counts it
-            const unsigned long long slot = wave_append_slot(a.ovf_count);
-            a.ovf_list[slot] = (uint32_t)r;
-            s.cL = s.cP = s.cC = s.cS = s.cH = s.cV = 0;
-        }
-        // ---- qualities: global -> LDS; score the parked hits and deliver them
-        if (DEFER) {
-            for (uint32_t g = 0; g < 64; g += GL) {
-                const uint64_t gb = __shfl(o0, (int)g), ge = __shfl(o1, (int)(g + GL - 1));
-                const bool mine = lane >= g && lane < g + GL && elig && !ovf && s.p_n;
-                if (!__any(mine)) continue;
-                uint32_t l0 = 0;
-                wave_lds_sync();
-                if (a.b.qual) l0 = stage_wave(stg, a.b.qual + gb, ge - gb, lane);
-                wave_lds_sync();
-                if (mine) flush_pending<W, SCORES, ALL>(a, s, sLL, LdsRow{stg, l0 + (uint32_t)(o0 - gb)});
-            }
-        }
-        if (elig && !ovf) {
-            cR = 1;
-            if (!ALL) {
-                a.info[r] = s.info;
-                if (SCORES) a.score[r] = s.iscore;
-            }
-        }
-        if (ALL && r < n) a.hit_cnt[r] = (elig && !ovf) ? s.nhit : 0u; // (a handed-over read: the repeat kernel writes it)
-    } else {
-        const uint64_t n_items = (uint64_t)*a.ovf_count;
-        // (every lane of a wave makes the same number of trips: the row lookups are wave-wide)
-        for (uint64_t it0 = (uint64_t)blockIdx.x * 256; it0 < n_items; it0 += (uint64_t)gridDim.x * 256) {
-            const uint64_t it = it0 + threadIdx.x;
-            const bool have = it < n_items;
-            const uint64_t r = have ? a.ovf_list[it] : 0;
-            const uint64_t o0 = a.b.off ? a.b.off[r] : r * (uint64_t)a.b.upatl;
-            const uint32_t patl = a.b.off ? (uint32_t)(a.b.off[r + 1] - o0) : a.b.upatl;
-            s.r = r; s.o0 = o0; s.patl = patl; s.nhit = 0;
-            if (have) {
-                pack_read<W>(GlobalRow{a.b.bases + o0}, patl, s.O); // (eligible: the matcher handed it over)
-                if (!ALL) {
-                    s.info = a.info[r];
-                    if (SCORES) s.iscore = a.score[r];
-                }
-            }
-            if (TK >= 3)
-                match_read_rows<W, SCORES, ALL, DEFER, TK == 4>(a, s, sLL, stg, have);
-            else if (have)
-                match_read<W, SCORES, ALL, FINE, DEFER>(a, s, sLL, q_pos, q_la, q_cur);
-            if (!have) continue;
-            cR++;
-            if (!ALL) {
-                a.info[r] = s.info;
-                if (SCORES) a.score[r] = s.iscore;
-            } else {
-                a.hit_cnt[r] = s.nhit;
-            }
+            if (mine) flush_pending<W, SCORES, ALL>(a, s, sLL, LdsRow{stg, l0 + (uint32_t)(o0 - gb)});
         }
     }
+    if (elig && !ovf) {
+        cR = 1;
+        if (!ALL) {
+            a.info[r] = s.info;
+            if (SCORES) a.score[r] = s.iscore;
+        }
+    }
+    if (ALL && r < n) a.hit_cnt[r] = (elig && !ovf) ? s.nhit : 0u; // (a handed-over read: the wave matcher writes it)
 
     // work counters: wave reduction, one atomic per wave and counter
     unsigned c[7] = {cR, s.cL, s.cP, s.cC, s.cS, s.cH, s.cV};
@@ -1086,90 +901,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
 }
 
 // ---------------------------------------------------------------------------
-// launcher
+// launcher of the instances of ONE read width W = RH_W (this file is compiled once per width, see the Makefile:
+// eight translation units build in parallel instead of one for minutes)
 // ---------------------------------------------------------------------------
-template <int W, int FINE>
-static void launch_match_wf(real_hip_ctx *ctx, const MatchArgs &a, bool all)
+#ifndef RH_W
+#error "compile with -DRH_W=<1..8>"
+#endif
+template <int W, int TK>
+static void launch_match_wt(real_hip_ctx *ctx, const MatchArgs &a, bool all)
 {
     dim3 grid((unsigned)((a.b.n_reads + 255) / 256)), block(256);
     const bool sc = ctx->prm.scores != 0;
     if (all) {
-        if (sc) hipLaunchKernelGGL((match_kernel<W, true, true, FINE, false>), grid, block, 0, ctx->stream, a);
-        else    hipLaunchKernelGGL((match_kernel<W, false, true, FINE, false>), grid, block, 0, ctx->stream, a);
+        if (sc) hipLaunchKernelGGL((match_kernel<W, true, true, TK>), grid, block, 0, ctx->stream, a);
+        else    hipLaunchKernelGGL((match_kernel<W, false, true, TK>), grid, block, 0, ctx->stream, a);
     } else {
-        if (sc) hipLaunchKernelGGL((match_kernel<W, true, false, FINE, false>), grid, block, 0, ctx->stream, a);
-        else    hipLaunchKernelGGL((match_kernel<W, false, false, FINE, false>), grid, block, 0, ctx->stream, a);
+        if (sc) hipLaunchKernelGGL((match_kernel<W, true, false, TK>), grid, block, 0, ctx->stream, a);
+        else    hipLaunchKernelGGL((match_kernel<W, false, false, TK>), grid, block, 0, ctx->stream, a);
     }
 }
-// reads the matcher handed over (scores on only): far fewer than the batch, so a fixed grid strides over them
-template <int W, int FINE>
-static void launch_repeat_wf(real_hip_ctx *ctx, const MatchArgs &a, bool all)
+#define RH_CAT2(a, b) a##b
+#define RH_CAT(a, b) RH_CAT2(a, b)
+void RH_CAT(rh_launch_match_w, RH_W)(real_hip_ctx *ctx, const MatchArgs &a, bool all)
 {
-    const uint64_t blocks = (a.b.n_reads + 255) / 256;
-    dim3 grid((unsigned)(blocks < 512 ? blocks : 512)), block(256); // (two workgroups per CU: the hand-over list is short)
-    if (all) hipLaunchKernelGGL((match_kernel<W, true, true, FINE, true>), grid, block, 0, ctx->stream, a);
-    else     hipLaunchKernelGGL((match_kernel<W, true, false, FINE, true>), grid, block, 0, ctx->stream, a);
+    if (a.ix.fine == 3 && !a.ix.pbits) launch_match_wt<RH_W, 4>(ctx, a, all);
+    else if (a.ix.fine == 3) launch_match_wt<RH_W, 3>(ctx, a, all);
+    else if (a.ix.fine) launch_match_wt<RH_W, 1>(ctx, a, all);
+    else launch_match_wt<RH_W, 0>(ctx, a, all);
 }
-template <int W>
-static void launch_match_w(real_hip_ctx *ctx, const MatchArgs &a, bool all, bool repeat)
-{
-    if (repeat) {
-        if (a.ix.fine == 3 && !a.ix.pbits) launch_repeat_wf<W, 4>(ctx, a, all);
-        else if (a.ix.fine == 3) launch_repeat_wf<W, 3>(ctx, a, all);
-        else if (a.ix.fine) launch_repeat_wf<W, 1>(ctx, a, all);
-        else launch_repeat_wf<W, 0>(ctx, a, all);
-        return;
-    }
-    if (a.ix.fine == 3 && !a.ix.pbits) launch_match_wf<W, 4>(ctx, a, all);
-    else if (a.ix.fine == 3) launch_match_wf<W, 3>(ctx, a, all);
-    else if (a.ix.fine) launch_match_wf<W, 1>(ctx, a, all);
-    else launch_match_wf<W, 0>(ctx, a, all);
-}
-
-static int launch_match_any(real_hip_ctx *ctx, const MatchArgs &a, bool all, bool repeat)
-{
-    switch (a.b.W) {
-    case 1: launch_match_w<1>(ctx, a, all, repeat); break;
-    case 2: launch_match_w<2>(ctx, a, all, repeat); break;
-    case 3: launch_match_w<3>(ctx, a, all, repeat); break;
-    case 4: launch_match_w<4>(ctx, a, all, repeat); break;
-    case 5: launch_match_w<5>(ctx, a, all, repeat); break;
-    case 6: launch_match_w<6>(ctx, a, all, repeat); break;
-    case 7: launch_match_w<7>(ctx, a, all, repeat); break;
-    case 8: launch_match_w<8>(ctx, a, all, repeat); break;
-    default: return rh_fail(ctx, REAL_HIP_E_UNSUPPORTED, "read longer than REAL_HIP_MAX_PATL", hipSuccess);
-    }
-    return REAL_HIP_OK;
-}
-
-int rh_launch_match(real_hip_ctx *ctx, const MatchArgs &args, bool all)
-{
-    if (!args.b.n_reads) return REAL_HIP_OK;
-    MatchArgs a = args;
-    const bool sc = ctx->prm.scores != 0;
-    int rc;
-    { // reads a wave stages at a time: their bytes (+ alignment skew, pad, one dword of over-read) fit its LDS region
-        const uint32_t maxlen = a.b.off ? 32u * a.b.W : a.b.upatl;
-        uint32_t gl = 64;
-        while (gl > 1 && (uint64_t)gl * maxlen + STG_PAD + 16 + 16 > stg_bytes((int)a.b.W, (int)a.ix.fine)) gl >>= 1;
-        a.b.gl = gl;
-    }
-    if (sc) { // hand-over list of the reads the matcher leaves to the repeat kernel
-        if ((rc = rh_reserve(ctx, ctx->ovf_list, a.b.n_reads * 4))) return rc;
-        if ((rc = rh_reserve(ctx, ctx->ovf_count, 8))) return rc;
-        a.ovf_list = (uint32_t *)ctx->ovf_list.p;
-        a.ovf_count = (unsigned long long *)ctx->ovf_count.p;
-        RH_HIP(ctx, hipMemsetAsync(ctx->ovf_count.p, 0, 8, ctx->stream));
-    }
-    rh_time_begin(ctx, ctx->stream, all ? REAL_HIP_K_MATCH_ALL : REAL_HIP_K_MATCH_UNIQUE);
-    if ((rc = launch_match_any(ctx, a, all, false))) return rc;
-    rh_time_end(ctx, ctx->stream);
-    RH_HIP(ctx, hipGetLastError());
-    if (sc) {
-        rh_time_begin(ctx, ctx->stream, REAL_HIP_K_MATCH_REPEAT);
-        if ((rc = launch_match_any(ctx, a, all, true))) return rc;
-        rh_time_end(ctx, ctx->stream);
-        RH_HIP(ctx, hipGetLastError());
-    }
-    return REAL_HIP_OK;
-}
+uint32_t RH_CAT(rh_stage_bytes_w, RH_W)(int tk) { return stg_bytes(RH_W, tk); }

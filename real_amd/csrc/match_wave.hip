@@ -1,0 +1,321 @@
+// match_wave.hip -- the wave-cooperative matcher: ONE WAVE owns one read.
+//
+// The per-read matcher (match_kernel.hip) gives every read one lane, as the reference gives it one thread
+// (match.hpp:383-413 is a serial loop over the equal range).  A read that lands on a low-complexity signature
+// -- an equal range of 10^5..10^6 entries in a real genome -- would keep that lane, and with it its wave, busy
+// for 0.1..1 s.  Such reads (an equal range or bucket scan longer than BIG_T entries; more verified locations or
+// update() events than a lane can park) are handed over to this kernel instead.  Here the 64 lanes of a wave take
+// 64 entries of the equal range at a time:
+//     entry -> partner filter (match.hpp:386 on the partner bits the entry carries) -> seed window on the text
+//           -> position / fragment / N checks (match.hpp:390-398) -> Hamming verify (RestMatch.hpp:39-81)
+//           -> score (ComputeScore.hpp:50-190), every lane for its own candidate;
+// the survivors are compacted with __ballot: in entry order they are folded into the read's record by the whole
+// wave (the fold is order dependent, SURVEY 8a10: lane order = entry order = the reference's candidate order), or
+// appended to the hit list behind one atomic (ballot + prefix popcount).  Lists and strands are walked in the
+// canonical order (strand, list 0..5, ascending position inside an equal range), so records, score bits, hit
+// lists and the work counters L, C, S, H are those of the reference.
+// All four table kinds are read here without their shortcuts (digests, fingerprints): bucket bounds, then the
+// entries themselves.
+#include "match_common.h"
+
+#define WV_W RH_MAXW // the read sits in registers, up to REAL_HIP_MAX_PATL bases
+
+struct WaveRange {
+    const uint2 *E;      // entries {key, pos} in an entry array, or
+    const uint32_t *row; // the 32 dwords of a bucket row (entries of 6 bytes behind the directory)
+    uint32_t lo, cnt;    // first entry, entries to look at
+    uint32_t key;        // what an entry's key is compared with
+    uint32_t mode;       // 0: array, member iff (e.x >> pbits) == key, then the partner filter on e.x & pmask (pbits != 0)
+                         // 1: row entries (narrow): partner filter on the 16 key bits
+                         // 2: row entries (wide): 16-bit fingerprint of the key
+                         // 3: overflow array of a row (narrow): partner filter on e.x & pmask
+                         // 4: overflow array of a row (wide): e.x == key
+    uint32_t partner;    // leading pbits of the read's partner signature s_b (modes 0, 1, 3)
+    uint32_t counted;    // members of the reference's equal range known without looking at the entries (rows, narrow)
+};
+
+__device__ __forceinline__ uint64_t pick4(uint64_t m0, uint64_t m1, uint64_t m2, uint64_t m3, uint32_t x)
+{
+    return x == 0 ? m0 : x == 1 ? m1 : x == 2 ? m2 : m3;
+}
+
+// the equal range of list la for the oriented read with seed halves (shi, slo); everything here is wave-uniform
+__device__ __forceinline__ WaveRange wave_lookup(const MatchArgs &a, uint64_t shi, uint64_t slo, int la)
+{
+    WaveRange R;
+    R.E = a.ix.ent[la]; R.row = nullptr; R.lo = 0; R.cnt = 0; R.key = 0; R.mode = 0; R.partner = 0; R.counted = 0;
+    const uint32_t bb = a.b_bits, l = a.l;
+    const uint64_t mb = (bb >= 64) ? ~0ull : ((1ull << bb) - 1);
+    const uint64_t m0 = shi >> bb, m1 = shi & mb, m2 = slo >> bb, m3 = slo & mb;
+    // s0..s5 = segments (0,1),(0,2),(0,3),(1,2),(1,3),(2,3), SignatureConstruction.hpp:62-67; partner = list 5-la
+    const uint32_t xa = (0x940u >> (2 * la)) & 3u, xc = (0xfb9u >> (2 * la)) & 3u;
+    const int lb = 5 - la;
+    const uint32_t xb = (0x940u >> (2 * lb)) & 3u, xd = (0xfb9u >> (2 * lb)) & 3u;
+    const uint64_t sa = (pick4(m0, m1, m2, m3, xa) << bb) | pick4(m0, m1, m2, m3, xc);
+    const uint64_t sb = (pick4(m0, m1, m2, m3, xb) << bb) | pick4(m0, m1, m2, m3, xd);
+    const uint32_t pbits = a.ix.pbits;
+    R.partner = pbits ? (uint32_t)(sb >> (l - pbits)) : 0u;
+    const uint32_t prefix = (uint32_t)(sa >> a.ix.pshift);
+    if (a.ix.fine != 3) {
+        // entry arrays in list order behind bucket starts (u32, or the .x of the 16-byte directory entries)
+        uint32_t lo, hi;
+        if (a.ix.fine == 0) { lo = a.ix.bkt[la][prefix]; hi = a.ix.bkt[la][prefix + 1]; }
+        else {
+            const uint4 *B = reinterpret_cast<const uint4 *>(a.ix.bkt[la]);
+            lo = B[prefix].x; hi = B[prefix + 1].x;
+        }
+        const uint32_t f = (uint32_t)((sa >> a.ix.fshift) & ((a.ix.fbits >= 32) ? 0xffffffffull : ((1ull << a.ix.fbits) - 1)));
+        // bounds of the key inside the bucket (entries of a bucket are sorted by key)
+        uint32_t x = lo, y = hi;
+        while (x < y) { const uint32_t mid = x + ((y - x) >> 1); if ((R.E[mid].x >> pbits) < f) x = mid + 1; else y = mid; }
+        const uint32_t first = x;
+        y = hi;
+        while (x < y) { const uint32_t mid = x + ((y - x) >> 1); if ((R.E[mid].x >> pbits) <= f) x = mid + 1; else y = mid; }
+        R.lo = first; R.cnt = x - first; R.key = f; R.mode = 0;
+        return R;
+    }
+    // bucket rows
+    const bool wide = pbits == 0;
+    uint32_t g, bucket;
+    if (!wide) {
+        const uint32_t gbits = a.ix.fbits;
+        bucket = (uint32_t)sa >> gbits; g = (uint32_t)sa & ((1u << gbits) - 1);
+        R.key = R.partner;
+    } else {
+        bucket = prefix;
+        R.key = (uint32_t)(sa >> a.ix.fshift);
+        g = R.key >> 28;
+    }
+    const uint32_t *row = a.ix.bkt[la] + (uint64_t)bucket * 32;
+    const uint32_t h0 = row[0], h1 = row[1];
+    if ((h0 & h1) != 0xffffffffu) { // simple bucket: sixteen 4-bit counts, entries of 6 bytes
+        uint32_t base = 0, cnt = 0;
+        for (uint32_t q = 0; q < 16; ++q) {
+            const uint32_t c = ((q < 8 ? h0 : h1) >> (4 * (q & 7))) & 15u;
+            if (q < g) base += c;
+            if (q == g) cnt = c;
+        }
+        R.row = row; R.lo = base; R.cnt = cnt; R.mode = wide ? 2u : 1u;
+    } else { // complex bucket: entries in the overflow array, sixteen 8-bit counts (255 = "255 or more")
+        const uint32_t o0 = row[2], tot = row[3];
+        uint32_t base = 0, cnt = 0;
+        bool sat = false;
+        for (uint32_t q = 0; q <= g; ++q) {
+            const uint32_t c = (row[4 + (q >> 2)] >> (8 * (q & 3))) & 255u;
+            sat = sat || c == 255u;
+            if (q < g) base += c; else cnt = c;
+        }
+        uint32_t first = o0 + base;
+        if (sat) { // bounds of the key group by binary search
+            const uint32_t gs = wide ? 28u : pbits;
+            uint32_t x = o0, y = o0 + tot;
+            while (x < y) { const uint32_t mid = x + ((y - x) >> 1); if ((R.E[mid].x >> gs) < g) x = mid + 1; else y = mid; }
+            first = x; y = o0 + tot;
+            while (x < y) { const uint32_t mid = x + ((y - x) >> 1); if ((R.E[mid].x >> gs) <= g) x = mid + 1; else y = mid; }
+            cnt = x - first;
+        }
+        R.lo = first; R.cnt = cnt; R.mode = wide ? 4u : 3u;
+    }
+    if (!wide) R.counted = R.cnt; // (wide: counted when the text confirms the membership)
+    return R;
+}
+
+template <bool SCORES, bool ALL>
+__global__ __launch_bounds__(256) void match_wave_kernel(MatchArgs a)
+{
+    constexpr int W = WV_W;
+    __shared__ double sLL[SCORES ? 1024 : 1];
+    if (SCORES) {
+        for (int i = threadIdx.x; i < 1024; i += 256) sLL[i] = a.LL[i];
+        __syncthreads();
+    }
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t n_items = (uint64_t)*a.ovf_count;
+    const uint64_t n_waves = (uint64_t)gridDim.x * 4;
+    const uint32_t l = a.l, bb = a.b_bits, pbits = a.ix.pbits, pmask = pbits ? ((1u << pbits) - 1) : 0u, p16 = pbits < 16 ? pbits : 16;
+    const uint64_t mb = (bb >= 64) ? ~0ull : ((1ull << bb) - 1);
+    const uint64_t *__restrict__ T = a.t.text;
+    unsigned cR = 0, cL = 0, cP = 0, cC = 0, cS = 0, cH = 0, cV = 0;
+
+    for (uint64_t it = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); it < n_items; it += n_waves) { // (wave-uniform trip count)
+        const uint64_t r = a.ovf_list[it];
+        const uint64_t o0 = a.b.off ? a.b.off[r] : r * (uint64_t)a.b.upatl;
+        const uint32_t patl = a.b.off ? (uint32_t)(a.b.off[r + 1] - o0) : a.b.upatl;
+        uint64_t O[W];
+        pack_read<W>(GlobalRow{a.b.bases + o0}, patl, O); // (eligible: the matcher handed it over); the same in every lane
+        const uint32_t nw = (patl + 31) >> 5;
+        const uint64_t lastmask = ~0ull << (64 - 2 * (patl - 32 * (nw - 1)));
+        const float eps = (float)(a.filter_mult * (double)patl); // RealOptions.hpp:74-77
+        uint64_t info = 0;
+        float iscore = 0.f;
+        if (!ALL) {
+            info = a.info[r];
+            if (SCORES) iscore = a.score[r];
+        }
+        uint32_t nhit = 0;
+        uint64_t shi, slo, rhi, rlo;
+        seed_halves<W>(O, l, shi, slo, rhi, rlo);
+        if (lane == 0) cR++;
+        for (int inv = 0; inv < 2; ++inv) {
+            if (inv) { // transposed pattern, Pattern.hpp:105-128
+                uint64_t Rv[W];
+                revcomp_words<W>(O, Rv, patl);
+#pragma unroll
+                for (int j = 0; j < W; ++j) O[j] = Rv[j];
+                shi = rhi; slo = rlo;
+            }
+            const uint32_t so = inv ? (patl - l) : 0u; // RestMatch::getMatchOffset, RestMatch.hpp:84-89
+#pragma unroll 1
+            for (int la = 0; la < 6; ++la) {
+                if (!ALL && !SCORES && la == 1) {
+                    // uni0s / uni0r early-out (matchUniqueImplementation.cpp:434-436, 470-472)
+                    const unsigned st = (unsigned)(info >> ST_SHIFT), er = (unsigned)(info >> ER_SHIFT) & 15;
+                    if (st == (unsigned)(inv ? ST_REVERSE : ST_STRAIGHT) && er == 0) break;
+                }
+                const WaveRange R = wave_lookup(a, shi, slo, la);
+                if (lane == 0) { cL++; cP += R.cnt; cC += R.counted; }
+                const uint32_t xa = (0x940u >> (2 * la)) & 3u, xc = (0xfb9u >> (2 * la)) & 3u;
+#pragma unroll 1
+                for (uint32_t c0 = 0; c0 < R.cnt; c0 += 64) {
+                    const uint32_t i = c0 + lane;
+                    bool cand = i < R.cnt;
+                    uint32_t rpos = 0;
+                    if (cand) {
+                        if (R.mode == 1 || R.mode == 2) { // 6 bytes at halfword 4 + 3 * (lo + i) of the row
+                            const uint32_t h = 4 + 3 * (R.lo + i);
+                            const uint32_t d0 = R.row[h >> 1], d1 = R.row[(h >> 1) + 1];
+                            const uint32_t key = (h & 1) ? (d0 >> 16) : (d0 & 0xffffu);
+                            rpos = (h & 1) ? d1 : ((d0 >> 16) | (d1 << 16));
+                            const uint32_t x = key ^ (R.key >> (pbits - p16));
+                            cand = R.mode == 2 ? (key == rh_fp16(R.key)) : (__popc(((x >> 1) | x) & 0x5555u) <= a.seedkmax);
+                        } else {
+                            const uint2 e = R.E[R.lo + i];
+                            rpos = e.y;
+                            if (R.mode == 4) cand = e.x == R.key;
+                            else if (R.mode == 0 && !pbits) cand = true; // (the bounds were found on the whole key)
+                            else {
+                                // seed popcount filter (match.hpp:386) on the partner symbols the entry carries: more than
+                                // seedkmax known mismatches => rejected without touching the text (exact: the full count can
+                                // only be larger)
+                                if (R.mode == 0) cC++; // a member of the reference's equal range
+                                const uint32_t x = (e.x & pmask) ^ R.partner;
+                                cand = __popc(((x >> 1) | x) & 0x55555555u) <= a.seedkmax;
+                            }
+                        }
+                    }
+                    // ---- seed window on the text, filters, Hamming distance: every lane for its own candidate
+                    bool hit = false;
+                    uint32_t pos = 0, total = 0, frag = 0, first = 0;
+                    float sc = 1.0f; // ComputeScore<...,false>, ComputeScore.hpp:31-45
+                    if (cand) {
+                        const uint64_t wi0 = rpos >> 5;
+                        const U64x2 tt = load2(T + wi0);
+                        const uint64_t t2 = (l > 32) ? T[wi0 + 2] : 0ull;
+                        const unsigned sh0 = 2u * (rpos & 31);
+                        const uint64_t xhi = extract_bits(tt.a, tt.b, t2, sh0, l) ^ shi;
+                        const uint64_t xlo = extract_bits(tt.a, tt.b, t2, sh0 + l, l) ^ slo;
+                        const uint64_t dhi = ((xhi >> 1) | xhi) & M55, dlo = ((xlo >> 1) | xlo) & M55;
+                        const uint32_t k0 = __popcll(dhi >> bb), k1 = __popcll(dhi & mb), k2 = __popcll(dlo >> bb), k3 = __popcll(dlo & mb);
+                        const bool z0 = !k0, z1 = !k1, z2 = !k2, z3 = !k3;
+                        // a member of list la's equal range iff both segments the list is keyed on are mismatch free
+                        const bool za = xa == 0 ? z0 : xa == 1 ? z1 : z2, zc = xc == 1 ? z1 : xc == 2 ? z2 : z3;
+                        bool ok = za && zc;
+                        if (ok && !pbits) cC++;
+                        const uint32_t seedk = k0 + k1 + k2 + k3; // = diffcountpair(s_b, list_b[p->ptr].sign), match.hpp:386
+                        ok = ok && seedk <= a.seedkmax;
+                        if (ok) cS++;
+                        ok = ok && rpos >= so; // match.hpp:393
+                        if (ok) {
+                            pos = rpos - so;
+                            cV++;
+                            ok = frag_valid(a.t, pos, patl, frag) && !(a.t.has_wild && !wild_free(a.t.wild, pos, patl));
+                        }
+                        if (ok) {
+                            // Hamming distance of the whole oriented read against text[pos, pos+patl)
+                            // = seedk + RestMatch::computeDistance (RestMatch.hpp:39-81)
+                            const uint64_t wi = pos >> 5;
+                            const unsigned sh = 2u * (pos & 31);
+                            uint64_t tw[W], t[W + 2];
+#pragma unroll
+                            for (int j = 0; j <= W; j += 2) {
+                                U64x2 p2 = {0ull, 0ull};
+                                if ((uint32_t)j <= nw) p2 = load2(T + wi + j);
+                                t[j] = p2.a; t[j + 1] = p2.b;
+                            }
+#pragma unroll
+                            for (int j = 0; j < W; ++j) {
+                                const uint64_t al = sh ? ((t[j] << sh) | (t[j + 1] >> (64 - sh))) : t[j];
+                                tw[j] = al;
+                                const uint64_t x = al ^ O[j];
+                                uint64_t d = ((x >> 1) | x) & M55;
+                                if ((uint32_t)j + 1 == nw) d &= lastmask;
+                                if ((uint32_t)j < nw) total += __popcll(d);
+                            }
+                            if (total <= a.totalkmax) {
+                                hit = true;
+                                cH++; // one updater::update call per list, match.hpp:411
+                                if (SCORES)
+                                    sc = score_location<W>(sLL, O, tw, patl, GlobalRow{a.b.qual ? a.b.qual + o0 : nullptr}, a.b.qual != nullptr, (uint32_t)inv);
+                                first = (z0 && z1) ? 0u : (z0 && z2) ? 1u : (z0 && z3) ? 2u : (z1 && z2) ? 3u : (z1 && z3) ? 4u : 5u;
+                            }
+                        }
+                    }
+                    // ---- the survivors, compacted by ballot, in entry order
+                    if (ALL) {
+                        // unifyMatches (matchAllImplementation.cpp:150-161) removes exact duplicates: a (strand, pos) is kept
+                        // from the first list whose two segments are mismatch free
+                        const bool keep = hit && first == (uint32_t)la;
+                        if (keep) {
+                            const unsigned long long slot = wave_append_slot(a.raw_count); // ballot + prefix popcount, one atomic
+                            if (slot < a.raw_cap) a.raw[slot] = make_uint4((uint32_t)r, pos, __float_as_uint(sc), total | ((uint32_t)inv << 8) | (frag << 16));
+                        }
+                        nhit += (uint32_t)__popcll(__ballot(keep));
+                    } else {
+                        unsigned long long hm = __ballot(hit);
+                        while (hm) { // UpdateUniqueInfo::update in candidate order; the record is wave-uniform
+                            const int j = __ffsll((long long)hm) - 1;
+                            hm &= hm - 1;
+                            fold_update<SCORES>(inv != 0, a.t.fileid, (uint32_t)__shfl((int)pos, j), (unsigned)__shfl((int)total, j), __shfl(sc, j), eps,
+                                                (unsigned)__shfl((int)frag, j), info, iscore);
+                        }
+                    }
+                }
+            }
+        }
+        if (lane == 0) {
+            if (!ALL) {
+                a.info[r] = info;
+                if (SCORES) a.score[r] = iscore;
+            } else {
+                a.hit_cnt[r] = nhit;
+            }
+        }
+    }
+
+    // work counters: wave reduction, one atomic per wave and counter; [7] = reads matched here
+    unsigned c[8] = {cR, cL, cP, cC, cS, cH, cV, cR};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        unsigned v = c[k];
+        for (int d = 32; d; d >>= 1) v += __shfl_xor((int)v, d);
+        if (lane == 0 && v)
+            atomicAdd(a.counters + (size_t)((blockIdx.x * 4u + (threadIdx.x >> 6)) & (RH_CSTRIPES - 1)) * 16 + k, (unsigned long long)v);
+    }
+}
+
+// the reads the matcher handed over: far fewer than the batch; a fixed grid of waves strides over the list, whose
+// length the kernel reads from device memory (no host round trip)
+void rh_launch_match_wave(real_hip_ctx *ctx, const MatchArgs &a, bool all)
+{
+    const uint64_t waves = a.b.n_reads; // (at most one wave per read of the batch)
+    const uint64_t blocks = (waves + 3) / 4;
+    dim3 grid((unsigned)(blocks < 2048 ? blocks : 2048)), block(256); // eight workgroups per CU
+    const bool sc = ctx->prm.scores != 0;
+    if (all) {
+        if (sc) hipLaunchKernelGGL((match_wave_kernel<true, true>), grid, block, 0, ctx->stream, a);
+        else    hipLaunchKernelGGL((match_wave_kernel<false, true>), grid, block, 0, ctx->stream, a);
+    } else {
+        if (sc) hipLaunchKernelGGL((match_wave_kernel<true, false>), grid, block, 0, ctx->stream, a);
+        else    hipLaunchKernelGGL((match_wave_kernel<false, false>), grid, block, 0, ctx->stream, a);
+    }
+}

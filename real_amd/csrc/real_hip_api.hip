@@ -522,7 +522,7 @@ extern "C" int real_hip_match_unique(real_hip_ctx *ctx, const real_hip_batch *b,
     }
     RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     rh_time_resolve(ctx);
-    return REAL_HIP_OK;
+    return rh_match_finish(ctx);
 }
 
 extern "C" int real_hip_match_all(real_hip_ctx *ctx, const real_hip_batch *b, real_hip_hit *out, uint64_t cap,
@@ -548,6 +548,7 @@ extern "C" int real_hip_match_all(real_hip_ctx *ctx, const real_hip_batch *b, re
         if ((rc = rh_launch_match(ctx, a, true))) return rc;
         RH_HIP(ctx, hipMemcpyAsync(&n_raw, ctx->raw_count.p, 8, hipMemcpyDeviceToHost, ctx->stream));
         RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if ((rc = rh_match_finish(ctx))) return rc;
     }
     if (n_out) *n_out = n_raw;
     if (n_raw > cap) return rh_fail(ctx, REAL_HIP_E_OVERFLOW, "hit buffer too small", hipSuccess);
@@ -606,7 +607,7 @@ extern "C" int real_hip_counters_get(real_hip_ctx *ctx, real_hip_counters *out, 
         for (int k = 0; k < 8; ++k) h[k] += all[st * 16 + k];
     if (out) {
         out->reads = h[0]; out->lookups = h[1]; out->probes = h[2]; out->candidates = h[3];
-        out->seedpass = h[4]; out->hits = h[5]; out->verified = h[6]; out->reserved = 0;
+        out->seedpass = h[4]; out->hits = h[5]; out->verified = h[6]; out->handed_over = h[7];
     }
     return REAL_HIP_OK;
 }

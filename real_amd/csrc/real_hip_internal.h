@@ -100,6 +100,7 @@ struct MatchArgs {
     // reads handed from the matcher to the repeat kernel (scores on)
     uint32_t *ovf_list;
     unsigned long long *ovf_count;
+    uint32_t *err_flags;   // bit 0: a read longer than the declared bound / offsets not monotone (nothing was staged for it)
     double   filter_mult;
     uint32_t l, q, b_bits, seedkmax, totalkmax;
 };
@@ -137,6 +138,7 @@ struct real_hip_ctx {
     // batch staging (host batches), hand-over list of the repeat kernel
     DevBuf s_bases, s_qual, s_off, s_info, s_score;
     DevBuf maxpatl, ovf_list, ovf_count;
+    unsigned long long h_match_state[2] = {0, 0}; // host copy of {reads handed over, error flags} of the last launch
     // read ingestion (read_parse.hip)
     DevBuf p_text, p_nl, p_scal, p_spans, p_off, p_len1, p_bases, p_qual;
     // matchAll workspace
@@ -186,6 +188,7 @@ struct RhTimer { // HIP events on the ctx stream around a group of launches
 
 // ---- kernels launchers (match_kernels.hip) -----------------------------------
 int rh_launch_match(real_hip_ctx *ctx, const MatchArgs &a, bool all);
+int rh_match_finish(real_hip_ctx *ctx); // after the stream was synchronised: errors the kernels flagged
 // asynchronous kernel timing (no host synchronisation at the launch site)
 void rh_time_begin(real_hip_ctx *ctx, hipStream_t st, int which);
 void rh_time_end(real_hip_ctx *ctx, hipStream_t st);

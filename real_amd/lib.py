@@ -64,10 +64,10 @@ class RealHipBuildStats(C.Structure):
 class RealHipCounters(C.Structure):
     _fields_ = [("reads", C.c_uint64), ("lookups", C.c_uint64), ("probes", C.c_uint64),
                 ("candidates", C.c_uint64), ("seedpass", C.c_uint64), ("hits", C.c_uint64),
-                ("verified", C.c_uint64), ("reserved", C.c_uint64)]
+                ("verified", C.c_uint64), ("handed_over", C.c_uint64)]
 
     def as_dict(self):
-        return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
 HIT_DTYPE = np.dtype([("read", "<u4"), ("pos", "<u4"), ("score", "<f4"), ("frag", "<u2"),

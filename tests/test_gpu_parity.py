@@ -301,3 +301,103 @@ def test_errors_are_loud():
     info, score = m.match_unique(np.full(40, 4, np.uint8), np.zeros(40, np.uint8), patl=20)
     assert np.all(info == 0)
     m.close()
+
+
+def _repeat_cliff_case(seedl, n_poly, n_copies):
+    """a random genome with (a) a poly-A run of n_poly bases -- n_poly windows with signature 0 in all six lists, every
+    one of them a verified hit of a poly-A read -- and (b) n_copies planted copies of one seed-length/2 word followed by
+    random bases: an equal range of n_copies entries in list 0 whose partner signatures differ"""
+    rng = np.random.default_rng(7 + seedl)
+    half = seedl // 2
+    parts = [rng.integers(0, 4, size=400_000, dtype=np.uint8), np.zeros(n_poly + seedl, dtype=np.uint8),
+             rng.integers(0, 4, size=100_000, dtype=np.uint8)]
+    word = rng.integers(0, 4, size=half, dtype=np.uint8)
+    tail = rng.integers(0, 4, size=(n_copies, 40 - half), dtype=np.uint8)
+    parts.append(np.concatenate([np.broadcast_to(word, (n_copies, half)), tail], axis=1).reshape(-1))
+    parts.append(rng.integers(0, 4, size=100_000, dtype=np.uint8))
+    sym = np.concatenate(parts)
+    frag = np.array([0, 250_000, sym.shape[0]], dtype=np.uint64)
+    g = synth.Genome(sym=sym, frag_start=frag, frag_names=[" a", " b"])
+    patl = 100
+    reads = []
+    planted0 = 400_000 + n_poly + seedl + 100_000
+    for i in range(12):
+        reads.append(np.zeros(patl, dtype=np.uint8))                                  # poly-A
+        reads.append(np.full(patl, 3, dtype=np.uint8))                                # poly-T: its reverse complement
+    for i in range(100):
+        p = planted0 + 40 * int(rng.integers(0, n_copies - 4))
+        r = sym[p:p + patl].copy()
+        if i % 2:
+            r = synth.revcomp(r)
+        if i % 3 == 0:
+            r[50 + i % 40] = (r[50 + i % 40] + 1) & 3
+        reads.append(r)
+    b2 = synth.sample_reads(g, 2000, patl, 0.02, seed=5)
+    bases = np.concatenate([np.concatenate(reads), b2.bases])
+    n = len(reads) + b2.n_reads
+    qual = np.concatenate([np.full(len(reads) * patl, 30, dtype=np.uint8), b2.qual])
+    offsets = np.arange(n + 1, dtype=np.uint64) * np.uint64(patl)
+    return g, bases, qual, offsets, patl
+
+
+@pytest.mark.parametrize("seedl,kind,pb,scores", [(32, 0, 0, 1), (16, 3, 13, 1), (16, 2, 13, 1), (32, 0, 0, 0)])
+def test_repeat_cliff_is_bit_exact_and_bounded_in_time(ora, seedl, kind, pb, scores):
+    """Reads on signatures with 10^5 entries: bit-exact against the oracle, and matched in bounded wall time.  One lane
+    walking such an equal range alone (as the reference's thread does, match.hpp:383-413) takes 0.1-1 s per lookup; a
+    wave walks it 64 entries at a time (match_wave.hip)."""
+    import time
+    g, bases, qual, offsets, patl = _repeat_cliff_case(seedl, 100_000, 60_000)
+    p = ora.make_params(seedl=seedl, seedkmax=2, totalkmax=3, scores=scores)
+    oinfo, oscore, octr = _oracle_unique(ora, None, g.sym, g.frag_start, seedl, 0, p, bases, qual, offsets)
+    m = UniqueMatcher(_opts(seedl, 2, 3, scores), prefix_bits=pb, table_kind=kind)
+    m.set_text_symbols(0, g.sym, g.frag_start)
+    m.build_index_block()
+    m.match_unique(bases, qual, offsets)                    # warm-up (allocations)
+    m.counters(reset=True)
+    for k in (0, 4):
+        m.kernel_time(k, reset=True)
+    t0 = time.perf_counter()
+    info, score = m.match_unique(bases, qual, offsets)
+    dt = time.perf_counter() - t0
+    _compare_unique(info, score, oinfo, oscore, scores)
+    c = m.counters()
+    for kk in ("reads", "lookups", "candidates", "seedpass", "hits"):
+        assert c[kk] == octr[kk], (kk, c[kk], octr[kk])
+    assert c["handed_over"] >= 24, c                         # the poly-A / poly-T reads at least
+    assert c["candidates"] > 24 * 100_000                    # the case is what it claims to be
+    assert dt < 0.5, "repeat-rich reads took %.3f s (lane-per-read kernel %.1f ms, wave-per-read kernel %.1f ms)" % (
+        dt, m.kernel_time(0)[0], m.kernel_time(4)[0])
+    m.close()
+
+
+@pytest.mark.parametrize("seedl,kind,pb", [(32, 0, 0), (16, 3, 13)])
+def test_repeat_cliff_match_all(ora, seedl, kind, pb):
+    """matchAll on the same case: 10^5 hits per read.  The wave-cooperative matcher appends them behind ballots, the
+    ordering pass sorts such a read's segment with a workgroup radix sort instead of the quadratic ranking."""
+    import time
+    g, bases, qual, offsets, patl = _repeat_cliff_case(seedl, 100_000, 60_000)
+    p = ora.make_params(seedl=seedl, seedkmax=2, totalkmax=2, scores=1)
+    og = ora.Genome(g.sym, g.frag_start)
+    ix = ora.Index(og, seedl)
+    ohits, ooff, octr = ora.match_all(og, ix, p, bases, qual, offsets)
+    m = AllMatcher(_opts(seedl, 2, 2, 1), prefix_bits=pb, table_kind=kind)
+    m.set_text_symbols(0, g.sym, g.frag_start)
+    m.build_index_block()
+    cap = int(ohits.shape[0]) + 1024
+    m.match_all(bases, qual, offsets, cap=cap)               # warm-up (allocations)
+    m.counters(reset=True)
+    for k in (1, 2, 4):
+        m.kernel_time(k, reset=True)
+    t0 = time.perf_counter()
+    hits, hoff = m.match_all(bases, qual, offsets, cap=cap)
+    dt = time.perf_counter() - t0
+    assert np.array_equal(hoff, ooff), "per-read hit counts differ"
+    assert int(np.diff(hoff.astype(np.int64)).max()) >= 90_000
+    for x, y in zip(_hits_tuple(hits), _hits_tuple(ohits)):
+        assert np.array_equal(x, y)
+    c = m.counters()
+    for k in ("reads", "lookups", "candidates", "seedpass", "hits"):
+        assert c[k] == octr[k], (k, c[k], octr[k])
+    assert dt < 1.0, "repeat-rich reads took %.3f s (lane-per-read kernel %.1f ms, wave-per-read kernel %.1f ms, ordering pass %.1f ms)" % (
+        dt, m.kernel_time(1)[0], m.kernel_time(4)[0], m.kernel_time(2)[0])
+    m.close()
