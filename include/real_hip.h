@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define REAL_HIP_ABI_VERSION 1
+#define REAL_HIP_ABI_VERSION 2
 
 typedef struct real_hip_ctx real_hip_ctx;
 
@@ -166,7 +166,16 @@ typedef struct real_hip_batch {
     const uint64_t *offsets;    /* n_reads+1 start offsets; NULL => uniform length patl  */
     uint32_t        patl;       /* uniform read length if offsets == NULL               */
     uint32_t        max_patl;   /* upper bound of read length when offsets != NULL and
-                                   on_device (0: library computes it)                   */
+                                   on_device (0: library computes it); a read that turns out
+                                   longer fails the call with REAL_HIP_E_INVALID          */
+    /* -- since ABI version 2 (struct_size tells; a version-1 struct of 48 bytes is still accepted) -- */
+    uint32_t        packed;     /* 1: bases holds 2 bits per base instead of a byte: base g of the
+                                   concatenated batch at bits 7-2(g%4)-1.. of byte g/4 (MSB first, the
+                                   packing of TemporaryFile.hpp:335-373); offsets / patl still count bases */
+    uint32_t        reserved;
+    const uint8_t  *nflags;     /* packed only, nullable: bit (i%8) of byte i/8 set => read i holds a symbol
+                                   > 3 (it cannot be packed) and is skipped as the reference skips it
+                                   (matchUniqueImplementation.cpp:376-394)                              */
 } real_hip_batch;
 
 /* matchUnique: replaces the loop over UniqueMatcher::match
@@ -180,6 +189,20 @@ typedef struct real_hip_batch {
  * score may be NULL iff !scores.  Synchronous on return.                      */
 int real_hip_match_unique(real_hip_ctx *ctx, const real_hip_batch *b,
                           uint64_t *info, float *score);
+
+/* Pipelined form for host batches -- the producer/consumer block ring of AsynchronousReader.hpp:181-259 as a
+ * two-slot ring: submit queues upload, kernels and download of one batch and returns; the upload of the next
+ * batch and the download of the previous records run beside the kernels.  A slot's batch, info and score must
+ * stay untouched until real_hip_wait(slot) has returned (its status is the batch's).  For the copies to be
+ * asynchronous the host memory has to be pinned: real_hip_host_alloc, or the caller's own hipHostRegister.
+ * fresh != 0: the records are initialised on the device (NoMatch, score -FLT_MAX: the state of
+ * uniqueinfo(numpat), matchUniqueImplementation.cpp:1094-1097) instead of being uploaded.                   */
+#define REAL_HIP_SLOTS 2
+int real_hip_match_unique_submit(real_hip_ctx *ctx, const real_hip_batch *b, uint64_t *info, float *score,
+                                 uint32_t slot, int fresh);
+int real_hip_wait(real_hip_ctx *ctx, uint32_t slot);
+void *real_hip_host_alloc(size_t bytes);   /* pinned host memory; NULL on failure */
+void  real_hip_host_free(void *p);
 
 /* matchAll: replaces AllMatcher::match + unifyMatches
  * (matchAllImplementation.cpp:261-355, :150-161) for the resident block.      */
@@ -221,6 +244,9 @@ typedef struct real_hip_parsed {
 } real_hip_parsed;
 int real_hip_parse_reads(real_hip_ctx *ctx, const char *text, uint64_t n_bytes, int text_on_device,
                          int fastq, int quality_offset, real_hip_parsed *out);
+/* copy of a device array the library returned (the spans of real_hip_parsed: what the output formatter needs
+ * beside the records) to host memory; synchronous                                                          */
+int real_hip_download(real_hip_ctx *ctx, const void *device_ptr, void *host_ptr, size_t bytes);
 
 /* ---- work counters: accumulated since the last reset ---------- */
 typedef struct real_hip_counters {

@@ -397,16 +397,18 @@ int rh_rows_unpack(real_hip_ctx *ctx, int list, uint2 *d_entries, uint32_t *d_st
 // scratch of one index build: ONE allocation for all six lists.  (hipMalloc / hipFree of tens of gigabytes cost
 // far more than the kernels of the build -- the driver clears and maps every page -- so the transients are laid
 // out once, by offset, and regions whose lifetimes do not overlap share their bytes.)
-//   sorted list    keys_b (n x sig_bytes) + vals_b (n x 4): output of the device sort / destination of the upload
-//   X              during the sort: unsorted keys + rocPRIM's temporary storage; afterwards (bucket rows only): the
-//                  full entry array {key, pos} the rows are cut from
+//   pair B         keys_b (n x sig_bytes) + vals_b (n x 4): destination of the upload (host-built lists); one of the
+//   pair A         keys_a + vals_x                          two buffers of the device sort (rocPRIM double buffers:
+//                  the sort ping-pongs between the pairs and needs no temporary of its own beyond histograms)
+//   entries        bucket rows only: the full entry array {key, pos} the rows are cut from lies over whichever pair
+//                  does NOT hold the sorted list
 //   tables         bucket starts; rows: overflow counts and their scan
 // Persistent outputs (rows / overflow entries, or entries / bucket tables) are allocations of their own.
 // ---------------------------------------------------------------------------
 struct BuildScratch {
     ScopedBuf arena;
     uint8_t *keys_a = nullptr, *keys_b = nullptr;
-    uint32_t *vals_b = nullptr;
+    uint32_t *vals_x = nullptr, *vals_b = nullptr;
     void *sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     uint2 *ent = nullptr;
@@ -417,12 +419,12 @@ struct BuildScratch {
 };
 
 template <typename K>
-static hipError_t sort_pairs(void *tmp, size_t &tmp_bytes, const K *kin, K *kout, const uint32_t *vin, uint32_t *vout, uint64_t n,
+static hipError_t sort_pairs(void *tmp, size_t &tmp_bytes, rocprim::double_buffer<K> &keys, rocprim::double_buffer<uint32_t> &vals, uint64_t n,
                              uint32_t bits, hipStream_t st)
 {
     // stable LSD radix sort over the signature bits: equal signatures keep ascending position, as the reference's
     // ParallelRadixSort (ParallelRadixSort.hpp:160-203) does
-    return rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, (size_t)n, 0u, bits, st);
+    return rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, vals, (size_t)n, 0u, bits, st);
 }
 
 static int plan_scratch(real_hip_ctx *ctx, BuildScratch &S, uint64_t n, unsigned sig_bytes, bool need_sort)
@@ -432,8 +434,10 @@ static int plan_scratch(real_hip_ctx *ctx, BuildScratch &S, uint64_t n, unsigned
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t sort_tmp = 0, scan_tmp = 0;
     if (need_sort && n) {
-        hipError_t e = sig_bytes == 4 ? sort_pairs<uint32_t>(nullptr, sort_tmp, nullptr, nullptr, nullptr, nullptr, n, l, ctx->stream)
-                                      : sort_pairs<uint64_t>(nullptr, sort_tmp, nullptr, nullptr, nullptr, nullptr, n, l, ctx->stream);
+        rocprim::double_buffer<uint32_t> v(nullptr, nullptr);
+        hipError_t e;
+        if (sig_bytes == 4) { rocprim::double_buffer<uint32_t> k(nullptr, nullptr); e = sort_pairs<uint32_t>(nullptr, sort_tmp, k, v, n, l, ctx->stream); }
+        else { rocprim::double_buffer<uint64_t> k(nullptr, nullptr); e = sort_pairs<uint64_t>(nullptr, sort_tmp, k, v, n, l, ctx->stream); }
         if (e != hipSuccess) return rh_fail(ctx, REAL_HIP_E_DEVICE, "radix sort (size query)", e);
     }
     const bool rows = ctx->fine == 3;
@@ -441,9 +445,11 @@ static int plan_scratch(real_hip_ctx *ctx, BuildScratch &S, uint64_t n, unsigned
         hipError_t e = rocprim::exclusive_scan(nullptr, scan_tmp, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, nb1, rocprim::plus<uint32_t>(), ctx->stream);
         if (e != hipSuccess) return rh_fail(ctx, REAL_HIP_E_DEVICE, "scan (size query)", e);
     }
-    const size_t o_keys_b = 0, o_vals_b = o_keys_b + al(nn * sig_bytes), o_x = o_vals_b + al(nn * 4);
-    size_t x = need_sort ? al(nn * sig_bytes) + al(sort_tmp ? sort_tmp : 8) : 0;
-    if (rows && al(nn * sizeof(uint2)) > x) x = al(nn * sizeof(uint2));
+    // (a pair = keys then values, back to back: the entry array of the rows lies over a whole pair, n x (sig_bytes + 4) >= n x 8)
+    const size_t pair = al(nn * sig_bytes + nn * 4);
+    const size_t o_keys_b = 0, o_vals_b = nn * sig_bytes, o_x = pair;
+    size_t x = need_sort ? pair + al(sort_tmp ? sort_tmp : 8) : 0;
+    if (rows && !need_sort) x = al(nn * sizeof(uint2)); // (host-built lists: no pair A, the entries get room of their own)
     const size_t o_bkt = o_x + x;
     const size_t o_ocnt = o_bkt + (ctx->fine ? al(nb1 * 4) : 0);       // (kind 0 keeps the bucket starts: an allocation of their own)
     const size_t o_ostart = o_ocnt + (rows ? al(nb1 * 4) : 0);
@@ -453,8 +459,8 @@ static int plan_scratch(real_hip_ctx *ctx, BuildScratch &S, uint64_t n, unsigned
     if (rc) return rc;
     uint8_t *base = (uint8_t *)S.arena.p;
     S.keys_b = base + o_keys_b; S.vals_b = (uint32_t *)(base + o_vals_b);
-    S.keys_a = base + o_x; S.sort_tmp = base + o_x + al(nn * sig_bytes); S.sort_tmp_bytes = sort_tmp;
-    S.ent = rows ? (uint2 *)(base + o_x) : nullptr;
+    S.keys_a = base + o_x; S.vals_x = (uint32_t *)(base + o_x + nn * sig_bytes); S.sort_tmp = base + o_x + pair; S.sort_tmp_bytes = sort_tmp;
+    S.ent = rows ? (uint2 *)(base + o_x) : nullptr; // (the device build moves it to the pair that is free after the sort)
     S.bkt = ctx->fine ? (uint32_t *)(base + o_bkt) : nullptr;
     S.ocnt = rows ? (uint32_t *)(base + o_ocnt) : nullptr;
     S.ostart = rows ? (uint32_t *)(base + o_ostart) : nullptr;
@@ -591,19 +597,30 @@ __global__ void keys_kernel(const uint64_t *__restrict__ T, const uint32_t *__re
     keys[j] = (K)window_signature(T, wpos[j], l, list);
 }
 
+// d_wpos: the window starts of the block in ascending order, or null = every window from first_window on (no N in the text)
 template <typename K>
-static int sort_list(real_hip_ctx *ctx, BuildScratch &S, int list, const uint32_t *d_wpos, uint64_t n)
+static int sort_list(real_hip_ctx *ctx, BuildScratch &S, int list, const uint32_t *d_wpos, uint64_t first_window, uint64_t n)
 {
     const uint32_t l = ctx->prm.seedl;
+    const void *d_sign = S.keys_b;
+    const uint32_t *d_pos = S.vals_b;
     if (n) {
         rh_time_begin(ctx, ctx->stream, REAL_HIP_K_INDEX);
+        // the values of the sort: a fresh copy of the window starts for every list (the sort clobbers both buffers)
+        if (d_wpos) RH_HIP(ctx, hipMemcpyAsync(S.vals_x, d_wpos, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        else hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, S.vals_x, first_window, n);
         hipLaunchKernelGGL(keys_kernel<K>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                           (const uint64_t *)ctx->text.p, d_wpos, n, l, list, (K *)S.keys_a);
+                           (const uint64_t *)ctx->text.p, (const uint32_t *)S.vals_x, n, l, list, (K *)S.keys_a);
+        rocprim::double_buffer<K> keys((K *)S.keys_a, (K *)S.keys_b);
+        rocprim::double_buffer<uint32_t> vals(S.vals_x, S.vals_b);
         size_t tmp = S.sort_tmp_bytes;
-        RH_HIP(ctx, sort_pairs<K>(S.sort_tmp, tmp, (const K *)S.keys_a, (K *)S.keys_b, d_wpos, S.vals_b, n, l, ctx->stream));
+        RH_HIP(ctx, sort_pairs<K>(S.sort_tmp, tmp, keys, vals, n, l, ctx->stream));
         rh_time_end(ctx, ctx->stream);
+        d_sign = keys.current(); d_pos = vals.current();
+        // the entry array of the rows goes over the pair the sorted list is NOT in
+        if (S.ent) S.ent = (uint2 *)((const void *)keys.current() == (const void *)S.keys_a ? S.keys_b : S.keys_a);
     }
-    return index_from_sorted(ctx, S, list, S.keys_b, S.vals_b, n, sizeof(K));
+    return index_from_sorted(ctx, S, list, d_sign, d_pos, n, sizeof(K));
 }
 
 int rh_index_build_device(real_hip_ctx *ctx, uint64_t first_window, uint64_t max_entries, uint64_t *n_entries,
@@ -619,16 +636,10 @@ int rh_index_build_device(real_hip_ctx *ctx, uint64_t first_window, uint64_t max
     int rc;
     // the tables of the previous block go first: their bytes are needed
     for (int k = 0; k < 6; ++k) { rh_release(ctx, ctx->ent[k]); rh_release(ctx, ctx->bkt[k]); }
-    if (ctx->n_wild == 0) {
+    if (ctx->n_wild == 0) { // every window from first_window on: the starts are generated, not stored
         cnt = (first_window < nwin_all) ? (nwin_all - first_window) : 0;
         if (cnt > max_entries) cnt = max_entries;
-        if ((rc = rh_reserve(ctx, ctx->vals_a, (cnt ? cnt : 1) * 4))) return rc;
-        rh_time_begin(ctx, ctx->stream, REAL_HIP_K_INDEX);
-        if (cnt)
-            hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream,
-                               (uint32_t *)ctx->vals_a.p, first_window, cnt);
-        rh_time_end(ctx, ctx->stream);
-        d_wpos = (const uint32_t *)ctx->vals_a.p;
+        d_wpos = nullptr;
     } else {
         // flags -> compacted ascending window starts (all blocks), then slice
         ScopedBuf flags(ctx), sel(ctx), dcount(ctx);
@@ -662,7 +673,7 @@ int rh_index_build_device(real_hip_ctx *ctx, uint64_t first_window, uint64_t max
         BuildScratch S(ctx);
         rc = plan_scratch(ctx, S, cnt, l <= 32 ? 4 : 8, true);
         for (int k = 0; k < 6 && !rc; ++k)
-            rc = (l <= 32) ? sort_list<uint32_t>(ctx, S, k, d_wpos, cnt) : sort_list<uint64_t>(ctx, S, k, d_wpos, cnt);
+            rc = (l <= 32) ? sort_list<uint32_t>(ctx, S, k, d_wpos, first_window, cnt) : sort_list<uint64_t>(ctx, S, k, d_wpos, first_window, cnt);
         if (!rc) RH_HIP(ctx, hipStreamSynchronize(ctx->stream)); // (before the scratch goes)
         if (rc == REAL_HIP_E_NOMEM && ctx->fine == 3 && ctx->prm.table_kind == 0 && !ctx->no_rows && attempt == 0) {
             // the rows did not fit after all (memory held by others): once more with directory tables

@@ -9,7 +9,7 @@
 RH_DECL_W(1) RH_DECL_W(2) RH_DECL_W(3) RH_DECL_W(4) RH_DECL_W(5) RH_DECL_W(6) RH_DECL_W(7) RH_DECL_W(8)
 void rh_launch_match_wave(real_hip_ctx *ctx, const MatchArgs &a, bool all);
 
-int rh_launch_match(real_hip_ctx *ctx, const MatchArgs &args, bool all)
+int rh_launch_match(real_hip_ctx *ctx, const MatchArgs &args, bool all, int state_slot)
 {
     if (!args.b.n_reads) return REAL_HIP_OK;
     MatchArgs a = args;
@@ -43,15 +43,15 @@ int rh_launch_match(real_hip_ctx *ctx, const MatchArgs &args, bool all)
     rh_launch_match_wave(ctx, a, all);
     rh_time_end(ctx, ctx->stream);
     RH_HIP(ctx, hipGetLastError());
-    RH_HIP(ctx, hipMemcpyAsync(ctx->h_match_state, ctx->ovf_count.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+    RH_HIP(ctx, hipMemcpyAsync(ctx->h_state + 2 * state_slot, ctx->ovf_count.p, 16, hipMemcpyDeviceToHost, ctx->stream));
     return REAL_HIP_OK;
 }
 
 // after the stream has been synchronised: what the kernels of the last launch reported
-int rh_match_finish(real_hip_ctx *ctx)
+int rh_match_finish(real_hip_ctx *ctx, int state_slot)
 {
-    const unsigned long long flags = ctx->h_match_state[1];
-    ctx->h_match_state[1] = 0;
+    const unsigned long long flags = ctx->h_state[2 * state_slot + 1];
+    ctx->h_state[2 * state_slot + 1] = 0;
     if (flags & 1u)
         return rh_fail(ctx, REAL_HIP_E_INVALID, "a read of the batch is longer than the declared max_patl (or REAL_HIP_MAX_PATL), or the device offsets are not monotone", hipSuccess);
     return REAL_HIP_OK;

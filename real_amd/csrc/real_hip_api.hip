@@ -89,13 +89,20 @@ void rh_time_end(real_hip_ctx *c, hipStream_t st)
 }
 void rh_time_resolve(real_hip_ctx *c)
 {
+    // (pairs whose end has not executed yet -- a batch still in flight in the other slot -- stay pending)
+    size_t keep = 0;
     for (auto &p : c->pending) {
-        float ms = 0.f;
-        if (p.a && p.b && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { c->k_ms[p.which] += ms; c->k_n[p.which] += 1; }
-        if (p.a) c->ev_pool.push_back(p.a);
-        if (p.b) c->ev_pool.push_back(p.b);
+        if (p.a && p.b && hipEventQuery(p.b) == hipSuccess) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { c->k_ms[p.which] += ms; c->k_n[p.which] += 1; }
+            c->ev_pool.push_back(p.a);
+            c->ev_pool.push_back(p.b);
+        } else {
+            c->pending[keep++] = p;
+        }
     }
-    c->pending.clear();
+    (void)hipGetLastError(); // (hipErrorNotReady of the queries)
+    c->pending.resize(keep);
 }
 
 extern "C" const char *real_hip_strerror(int s)
@@ -185,6 +192,8 @@ extern "C" int real_hip_create(real_hip_ctx **out, const real_hip_params *p)
         if (hipSetDevice(c->device) != hipSuccess) { rc = REAL_HIP_E_DEVICE; break; }
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = REAL_HIP_E_DEVICE; break; }
         if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { rc = REAL_HIP_E_DEVICE; break; }
+        if (hipHostMalloc((void **)&c->h_state, 3 * 2 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) { rc = REAL_HIP_E_NOMEM; break; }
+        memset(c->h_state, 0, 3 * 2 * sizeof(unsigned long long));
         if ((rc = rh_reserve(c, c->LL, 1024 * sizeof(double)))) break;
         if ((rc = rh_reserve(c, c->counters, (size_t)(RH_CSTRIPES + 1) * 16 * sizeof(uint64_t)))) break;
         if (hipMemcpy(c->LL.p, p->LL, 1024 * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { rc = REAL_HIP_E_DEVICE; break; }
@@ -203,10 +212,25 @@ extern "C" void real_hip_destroy(real_hip_ctx *c)
     DevBuf *all[] = {&c->text, &c->wild, &c->frag, &c->LL, &c->counters, &c->s_bases, &c->s_qual, &c->s_off, &c->s_info,
                      &c->s_score, &c->maxpatl, &c->ovf_list, &c->ovf_count, &c->raw, &c->raw_count, &c->hit_cnt, &c->big_list, &c->p_text, &c->p_nl, &c->p_scal, &c->p_spans, &c->p_off,
                      &c->p_len1, &c->p_bases, &c->p_qual, &c->keys_a,
-                     &c->keys_b, &c->vals_a, &c->vals_b, &c->sort_tmp, &c->hit_off, &c->s_hits};
+                     &c->keys_b, &c->vals_a, &c->vals_b, &c->sort_tmp, &c->hit_off, &c->s_hits, &c->s_nflags, &c->unpacked};
     for (DevBuf *b : all) rh_release(*b);
     for (int k = 0; k < 6; ++k) { rh_release(c->ent[k]); rh_release(c->bkt[k]); }
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    if (c->down_stream) (void)hipStreamSynchronize(c->down_stream);
+    for (int i = 0; i < REAL_HIP_SLOTS; ++i) {
+        RhSlot &S = c->slot[i];
+        DevBuf *sb[] = {&S.bases, &S.qual, &S.off, &S.nflags, &S.info, &S.score};
+        for (DevBuf *b : sb) rh_release(*b);
+        if (S.up) (void)hipEventDestroy(S.up);
+        if (S.matched) (void)hipEventDestroy(S.matched);
+        if (S.done) (void)hipEventDestroy(S.done);
+    }
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->down_stream) (void)hipStreamDestroy(c->down_stream);
+    if (c->h_state) (void)hipHostFree(c->h_state);
     rh_time_resolve(c);
+    for (auto &p : c->pending) { if (p.a) (void)hipEventDestroy(p.a); if (p.b) (void)hipEventDestroy(p.b); }
+    c->pending.clear();
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -420,52 +444,91 @@ struct Staged {
     const uint64_t *off = nullptr;
     uint32_t upatl = 0, maxpatl = 0, W = 0;
 };
+// device buffers a host batch is copied into: the ctx's own (synchronous calls) or those of a slot (submit / wait)
+struct StageBufs {
+    DevBuf *bases, *qual, *off, *nflags;
+};
 
-static int stage_batch(real_hip_ctx *ctx, const real_hip_batch *b, Staged &s)
+// the batch struct of ABI version 1 ended behind max_patl
+#define RH_BATCH_V1_SIZE 48u
+static int batch_view(real_hip_ctx *ctx, const real_hip_batch *b, real_hip_batch &v)
 {
-    if (!b || b->struct_size != sizeof(real_hip_batch)) return rh_fail(ctx, REAL_HIP_E_INVALID, "batch struct_size", hipSuccess);
+    if (!b || (b->struct_size != sizeof(real_hip_batch) && b->struct_size != RH_BATCH_V1_SIZE))
+        return rh_fail(ctx, REAL_HIP_E_INVALID, "batch struct_size", hipSuccess);
+    memset(&v, 0, sizeof v);
+    memcpy(&v, b, b->struct_size);
+    return REAL_HIP_OK;
+}
+
+// Uploads (host batches; on `up`, which is ctx->stream for the synchronous calls and the copy stream for submitted ones)
+// and, on ctx->stream, unpacks 2-bit packed bases.  After it the arrays of `s` are valid for kernels on ctx->stream.
+static int stage_batch(real_hip_ctx *ctx, const real_hip_batch &b, Staged &s, const StageBufs &sb, hipStream_t up, hipEvent_t up_done)
+{
     if (!ctx->have_text || !ctx->have_index) return rh_fail(ctx, REAL_HIP_E_STATE, "text and index must be set", hipSuccess);
-    if (b->n_reads > 0xffffffffull) return rh_fail(ctx, REAL_HIP_E_INVALID, "more than 2^32 reads in one batch", hipSuccess);
-    const uint64_t n = b->n_reads;
+    if (b.n_reads > 0xffffffffull) return rh_fail(ctx, REAL_HIP_E_INVALID, "more than 2^32 reads in one batch", hipSuccess);
+    const uint64_t n = b.n_reads;
     if (!n) return REAL_HIP_OK;
-    if (!b->bases) return rh_fail(ctx, REAL_HIP_E_INVALID, "null bases", hipSuccess);
+    if (!b.bases) return rh_fail(ctx, REAL_HIP_E_INVALID, "null bases", hipSuccess);
+    if (b.nflags && !b.packed) return rh_fail(ctx, REAL_HIP_E_INVALID, "nflags belong to packed batches (unpacked ones carry symbol 4)", hipSuccess);
     int rc;
     uint64_t total = 0;
-    if (b->offsets) {
-        if (b->on_device) {
-            s.off = b->offsets;
-            s.maxpatl = b->max_patl;
+    if (b.offsets) {
+        if (b.on_device) {
+            s.off = b.offsets;
+            s.maxpatl = b.max_patl;
             if (!s.maxpatl && (rc = rh_max_patl(ctx, s.off, n, &s.maxpatl))) return rc;
+            if (b.packed) { // symbols of the batch = its last offset
+                RH_HIP(ctx, hipMemcpyAsync(&total, s.off + n, 8, hipMemcpyDeviceToHost, ctx->stream));
+                RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            }
         } else {
             for (uint64_t i = 0; i < n; ++i) {
-                if (b->offsets[i + 1] < b->offsets[i]) return rh_fail(ctx, REAL_HIP_E_INVALID, "offsets not monotone", hipSuccess);
-                uint64_t len = b->offsets[i + 1] - b->offsets[i];
+                if (b.offsets[i + 1] < b.offsets[i]) return rh_fail(ctx, REAL_HIP_E_INVALID, "offsets not monotone", hipSuccess);
+                uint64_t len = b.offsets[i + 1] - b.offsets[i];
                 if (len > s.maxpatl) s.maxpatl = (uint32_t)(len > 0xffffffffull ? 0xffffffffull : len);
             }
-            total = b->offsets[n];
-            if ((rc = rh_reserve(ctx, ctx->s_off, (n + 1) * 8))) return rc;
-            RH_HIP(ctx, hipMemcpyAsync(ctx->s_off.p, b->offsets, (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-            s.off = (const uint64_t *)ctx->s_off.p;
+            total = b.offsets[n];
+            if ((rc = rh_reserve(ctx, *sb.off, (n + 1) * 8))) return rc;
+            RH_HIP(ctx, hipMemcpyAsync(sb.off->p, b.offsets, (n + 1) * 8, hipMemcpyHostToDevice, up));
+            s.off = (const uint64_t *)sb.off->p;
         }
     } else {
-        s.upatl = b->patl; s.maxpatl = b->patl;
-        total = n * (uint64_t)b->patl;
-    }
-    if (b->on_device) {
-        s.bases = b->bases; s.qual = b->qual;
-    } else {
-        if ((rc = rh_reserve(ctx, ctx->s_bases, total ? total : 1))) return rc;
-        RH_HIP(ctx, hipMemcpyAsync(ctx->s_bases.p, b->bases, total, hipMemcpyHostToDevice, ctx->stream));
-        s.bases = (const uint8_t *)ctx->s_bases.p;
-        if (b->qual) {
-            if ((rc = rh_reserve(ctx, ctx->s_qual, total ? total : 1))) return rc;
-            RH_HIP(ctx, hipMemcpyAsync(ctx->s_qual.p, b->qual, total, hipMemcpyHostToDevice, ctx->stream));
-            s.qual = (const uint8_t *)ctx->s_qual.p;
-        }
+        s.upatl = b.patl; s.maxpatl = b.patl;
+        total = n * (uint64_t)b.patl;
     }
     // Reads longer than the register budget cannot be matched; the reference has no such
     // limit (RestWordBuffer grows), so this is an explicit, loud error and not a skip.
     if (s.maxpatl > REAL_HIP_MAX_PATL) return rh_fail(ctx, REAL_HIP_E_UNSUPPORTED, "read longer than REAL_HIP_MAX_PATL", hipSuccess);
+    const uint64_t base_bytes = b.packed ? (total + 3) / 4 : total;
+    const uint8_t *d_bases = b.bases, *d_flags = b.nflags;
+    if (b.on_device) {
+        s.qual = b.qual;
+    } else {
+        if ((rc = rh_reserve(ctx, *sb.bases, (base_bytes ? base_bytes : 1) + 16))) return rc;
+        RH_HIP(ctx, hipMemcpyAsync(sb.bases->p, b.bases, base_bytes, hipMemcpyHostToDevice, up));
+        d_bases = (const uint8_t *)sb.bases->p;
+        if (b.qual) {
+            if ((rc = rh_reserve(ctx, *sb.qual, total ? total : 1))) return rc;
+            RH_HIP(ctx, hipMemcpyAsync(sb.qual->p, b.qual, total, hipMemcpyHostToDevice, up));
+            s.qual = (const uint8_t *)sb.qual->p;
+        }
+        if (b.nflags) {
+            if ((rc = rh_reserve(ctx, *sb.nflags, (n + 7) / 8))) return rc;
+            RH_HIP(ctx, hipMemcpyAsync(sb.nflags->p, b.nflags, (n + 7) / 8, hipMemcpyHostToDevice, up));
+            d_flags = (const uint8_t *)sb.nflags->p;
+        }
+    }
+    if (up != ctx->stream) { // the kernels wait for the upload, the host does not
+        RH_HIP(ctx, hipEventRecord(up_done, up));
+        RH_HIP(ctx, hipStreamWaitEvent(ctx->stream, up_done, 0));
+    }
+    if (b.packed) {
+        if ((rc = rh_reserve(ctx, ctx->unpacked, (total ? total : 1) + 16))) return rc;
+        if ((rc = rh_unpack_bases(ctx, d_bases, total, d_flags, s.off, s.upatl, n, (uint8_t *)ctx->unpacked.p))) return rc;
+        s.bases = (const uint8_t *)ctx->unpacked.p;
+    } else {
+        s.bases = d_bases;
+    }
     s.W = (s.maxpatl + 31) / 32;
     if (s.W < 1) s.W = 1;
     return REAL_HIP_OK;
@@ -494,8 +557,11 @@ extern "C" int real_hip_match_unique(real_hip_ctx *ctx, const real_hip_batch *b,
 {
     RH_ENTER(ctx);
     Staged s;
-    int rc = stage_batch(ctx, b, s);
+    real_hip_batch bv;
+    int rc = batch_view(ctx, b, bv);
     if (rc) return rc;
+    b = &bv;
+    if ((rc = stage_batch(ctx, bv, s, StageBufs{&ctx->s_bases, &ctx->s_qual, &ctx->s_off, &ctx->s_nflags}, ctx->stream, nullptr))) return rc;
     const uint64_t n = b->n_reads;
     if (!n) return REAL_HIP_OK;
     const bool sc = ctx->prm.scores != 0;
@@ -515,14 +581,108 @@ extern "C" int real_hip_match_unique(real_hip_ctx *ctx, const real_hip_batch *b,
     MatchArgs a;
     fill_args(ctx, s, n, a);
     a.info = d_info; a.score = d_score;
-    if ((rc = rh_launch_match(ctx, a, false))) return rc;
+    if ((rc = rh_launch_match(ctx, a, false, 2))) return rc;
     if (b->on_device != 1) { // outputs in host memory
         RH_HIP(ctx, hipMemcpyAsync(info, d_info, n * 8, hipMemcpyDeviceToHost, ctx->stream));
         if (sc) RH_HIP(ctx, hipMemcpyAsync(score, d_score, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     }
     RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     rh_time_resolve(ctx);
-    return rh_match_finish(ctx);
+    return rh_match_finish(ctx, 2);
+}
+
+// ---------------------------------------------------------------------------
+// pipelined host batches: submit / wait over two slots.  The upload of batch k+1 (copy stream) and the download of
+// the records of batch k-1 (download stream) run beside the kernels of batch k (ctx stream); the counterpart of the
+// reference's producer / consumer block ring (AsynchronousReader.hpp:181-259).
+// ---------------------------------------------------------------------------
+__global__ void fill_f32_kernel(float *p, uint64_t n, float v)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+static int pipeline_init(real_hip_ctx *ctx)
+{
+    if (ctx->copy_stream) return REAL_HIP_OK;
+    RH_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    RH_HIP(ctx, hipStreamCreateWithFlags(&ctx->down_stream, hipStreamNonBlocking));
+    for (int i = 0; i < REAL_HIP_SLOTS; ++i) {
+        RH_HIP(ctx, hipEventCreateWithFlags(&ctx->slot[i].up, hipEventDisableTiming));
+        RH_HIP(ctx, hipEventCreateWithFlags(&ctx->slot[i].matched, hipEventDisableTiming));
+        RH_HIP(ctx, hipEventCreateWithFlags(&ctx->slot[i].done, hipEventDisableTiming));
+    }
+    return REAL_HIP_OK;
+}
+
+extern "C" int real_hip_match_unique_submit(real_hip_ctx *ctx, const real_hip_batch *b, uint64_t *info, float *score, uint32_t slot, int fresh)
+{
+    RH_ENTER(ctx);
+    if (slot >= REAL_HIP_SLOTS) return rh_fail(ctx, REAL_HIP_E_INVALID, "slot", hipSuccess);
+    RhSlot &S = ctx->slot[slot];
+    if (S.busy) return rh_fail(ctx, REAL_HIP_E_STATE, "slot in flight: real_hip_wait first", hipSuccess);
+    real_hip_batch bv;
+    int rc = batch_view(ctx, b, bv);
+    if (rc) return rc;
+    if (bv.on_device) return rh_fail(ctx, REAL_HIP_E_INVALID, "submit takes host batches (device batches: the synchronous calls)", hipSuccess);
+    const uint64_t n = bv.n_reads;
+    const bool sc = ctx->prm.scores != 0;
+    if (n && (!info || (sc && !score))) return rh_fail(ctx, REAL_HIP_E_INVALID, "null info/score", hipSuccess);
+    if ((rc = pipeline_init(ctx))) return rc;
+    S.n = n; S.status = REAL_HIP_OK;
+    if (!n) { S.busy = true; S.empty = true; return REAL_HIP_OK; }
+    S.empty = false;
+    // records: uploaded (they are in/out: folds compose across genome blocks), or initialised on the device (fresh:
+    // uniqueinfo(numpat), matchUniqueImplementation.cpp:1094-1097 -- NoMatch, score -FLT_MAX)
+    if ((rc = rh_reserve(ctx, S.info, n * 8))) return rc;
+    if (sc && (rc = rh_reserve(ctx, S.score, n * 4))) return rc;
+    if (fresh) {
+        RH_HIP(ctx, hipMemsetAsync(S.info.p, 0, n * 8, ctx->copy_stream));
+        if (sc) hipLaunchKernelGGL(fill_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->copy_stream, (float *)S.score.p, n, -3.402823466e+38f);
+    } else {
+        RH_HIP(ctx, hipMemcpyAsync(S.info.p, info, n * 8, hipMemcpyHostToDevice, ctx->copy_stream));
+        if (sc) RH_HIP(ctx, hipMemcpyAsync(S.score.p, score, n * 4, hipMemcpyHostToDevice, ctx->copy_stream));
+    }
+    Staged s;
+    if ((rc = stage_batch(ctx, bv, s, StageBufs{&S.bases, &S.qual, &S.off, &S.nflags}, ctx->copy_stream, S.up))) return rc;
+    MatchArgs a;
+    fill_args(ctx, s, n, a);
+    a.info = (uint64_t *)S.info.p; a.score = (float *)S.score.p;
+    ctx->time_slot = (int)slot;
+    rc = rh_launch_match(ctx, a, false, (int)slot);
+    ctx->time_slot = -1;
+    if (rc) return rc;
+    RH_HIP(ctx, hipEventRecord(S.matched, ctx->stream));
+    RH_HIP(ctx, hipStreamWaitEvent(ctx->down_stream, S.matched, 0));
+    RH_HIP(ctx, hipMemcpyAsync(info, S.info.p, n * 8, hipMemcpyDeviceToHost, ctx->down_stream));
+    if (sc) RH_HIP(ctx, hipMemcpyAsync(score, S.score.p, n * 4, hipMemcpyDeviceToHost, ctx->down_stream));
+    RH_HIP(ctx, hipEventRecord(S.done, ctx->down_stream));
+    S.busy = true;
+    return REAL_HIP_OK;
+}
+
+extern "C" int real_hip_wait(real_hip_ctx *ctx, uint32_t slot)
+{
+    RH_ENTER(ctx);
+    if (slot >= REAL_HIP_SLOTS) return rh_fail(ctx, REAL_HIP_E_INVALID, "slot", hipSuccess);
+    RhSlot &S = ctx->slot[slot];
+    if (!S.busy) return REAL_HIP_OK;
+    S.busy = false;
+    if (S.empty) return REAL_HIP_OK;
+    RH_HIP(ctx, hipEventSynchronize(S.done));
+    rh_time_resolve(ctx);
+    return rh_match_finish(ctx, (int)slot);
+}
+
+extern "C" void *real_hip_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+extern "C" void real_hip_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
 }
 
 extern "C" int real_hip_match_all(real_hip_ctx *ctx, const real_hip_batch *b, real_hip_hit *out, uint64_t cap,
@@ -530,8 +690,11 @@ extern "C" int real_hip_match_all(real_hip_ctx *ctx, const real_hip_batch *b, re
 {
     RH_ENTER(ctx);
     Staged s;
-    int rc = stage_batch(ctx, b, s);
+    real_hip_batch bv;
+    int rc = batch_view(ctx, b, bv);
     if (rc) return rc;
+    b = &bv;
+    if ((rc = stage_batch(ctx, bv, s, StageBufs{&ctx->s_bases, &ctx->s_qual, &ctx->s_off, &ctx->s_nflags}, ctx->stream, nullptr))) return rc;
     const uint64_t n = b->n_reads;
     if (n_out) *n_out = 0;
     if (cap > 0xffffffffull) cap = 0xffffffffull; // record indices are 32 bit inside the post-pass
@@ -545,10 +708,10 @@ extern "C" int real_hip_match_all(real_hip_ctx *ctx, const real_hip_batch *b, re
         if ((rc = rh_reserve(ctx, ctx->hit_cnt, (n + 1) * 4))) return rc;
         a.raw = (uint4 *)ctx->raw.p; a.raw_count = (unsigned long long *)ctx->raw_count.p; a.raw_cap = cap;
         a.hit_cnt = (uint32_t *)ctx->hit_cnt.p;
-        if ((rc = rh_launch_match(ctx, a, true))) return rc;
+        if ((rc = rh_launch_match(ctx, a, true, 2))) return rc;
         RH_HIP(ctx, hipMemcpyAsync(&n_raw, ctx->raw_count.p, 8, hipMemcpyDeviceToHost, ctx->stream));
         RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if ((rc = rh_match_finish(ctx))) return rc;
+        if ((rc = rh_match_finish(ctx, 2))) return rc;
     }
     if (n_out) *n_out = n_raw;
     if (n_raw > cap) return rh_fail(ctx, REAL_HIP_E_OVERFLOW, "hit buffer too small", hipSuccess);
@@ -590,6 +753,15 @@ extern "C" int real_hip_parse_reads(real_hip_ctx *ctx, const char *text, uint64_
     }
     RhTimer tm(ctx, REAL_HIP_K_PARSE);
     return rh_parse_reads(ctx, d_text, n_bytes, fastq, quality_offset, out);
+}
+
+extern "C" int real_hip_download(real_hip_ctx *ctx, const void *device_ptr, void *host_ptr, size_t bytes)
+{
+    RH_ENTER(ctx);
+    if (bytes && (!device_ptr || !host_ptr)) return rh_fail(ctx, REAL_HIP_E_INVALID, "null pointer", hipSuccess);
+    if (bytes) RH_HIP(ctx, hipMemcpyAsync(host_ptr, device_ptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return REAL_HIP_OK;
 }
 
 // ---------------------------------------------------------------------------

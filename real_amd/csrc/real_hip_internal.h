@@ -111,6 +111,15 @@ struct DevBuf {
     size_t cap = 0;
 };
 
+// one slot of the submit / wait pipeline: device copies of a host batch and its records
+struct RhSlot {
+    DevBuf bases, qual, off, nflags, info, score;
+    hipEvent_t up = nullptr, matched = nullptr, done = nullptr;
+    uint64_t n = 0;
+    int status = 0;
+    bool busy = false, empty = false;
+};
+
 struct real_hip_ctx {
     real_hip_params prm;
     int device = 0;
@@ -136,9 +145,13 @@ struct real_hip_ctx {
     DevBuf LL, counters;
 
     // batch staging (host batches), hand-over list of the repeat kernel
-    DevBuf s_bases, s_qual, s_off, s_info, s_score;
+    DevBuf s_bases, s_qual, s_off, s_info, s_score, s_nflags;
+    DevBuf unpacked;                                // byte symbols of a 2-bit packed batch (one batch at a time: the kernels of a ctx run in order)
+    RhSlot slot[REAL_HIP_SLOTS];                    // submit / wait
+    hipStream_t copy_stream = nullptr, down_stream = nullptr;
+    int time_slot = -1;
     DevBuf maxpatl, ovf_list, ovf_count;
-    unsigned long long h_match_state[2] = {0, 0}; // host copy of {reads handed over, error flags} of the last launch
+    unsigned long long *h_state = nullptr; // pinned: {reads handed over, error flags} of the last launch of slot 0, slot 1, the synchronous calls
     // read ingestion (read_parse.hip)
     DevBuf p_text, p_nl, p_scal, p_spans, p_off, p_len1, p_bases, p_qual;
     // matchAll workspace
@@ -187,8 +200,10 @@ struct RhTimer { // HIP events on the ctx stream around a group of launches
 };
 
 // ---- kernels launchers (match_kernels.hip) -----------------------------------
-int rh_launch_match(real_hip_ctx *ctx, const MatchArgs &a, bool all);
-int rh_match_finish(real_hip_ctx *ctx); // after the stream was synchronised: errors the kernels flagged
+int rh_launch_match(real_hip_ctx *ctx, const MatchArgs &a, bool all, int state_slot);
+int rh_match_finish(real_hip_ctx *ctx, int state_slot); // after the launch has completed: errors the kernels flagged
+int rh_unpack_bases(real_hip_ctx *ctx, const uint8_t *d_packed, uint64_t n_symbols, const uint8_t *d_nflags, const uint64_t *d_off,
+                    uint32_t upatl, uint64_t n_reads, uint8_t *d_out);
 // asynchronous kernel timing (no host synchronisation at the launch site)
 void rh_time_begin(real_hip_ctx *ctx, hipStream_t st, int which);
 void rh_time_end(real_hip_ctx *ctx, hipStream_t st);

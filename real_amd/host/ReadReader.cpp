@@ -3,11 +3,12 @@
 #include <cctype>
 #include <stdexcept>
 
-ReadReader::ReadReader(const std::string &filename, bool fastq, int qualityOffset)
-    : f_(nullptr), fastq_(fastq), qoff_(qualityOffset), marker_(fastq ? '@' : '>'), buf_(1 << 22)
+ReadReader::ReadReader(const std::string &filename, bool fastq, int qualityOffset, uint64_t start_offset, uint64_t first_id)
+    : f_(nullptr), fastq_(fastq), qoff_(qualityOffset), marker_(fastq ? '@' : '>'), nextid_(first_id), buf_(1 << 22)
 {
     f_ = (filename == "-") ? stdin : fopen(filename.c_str(), "rb");
     if (!f_) throw std::runtime_error("Unable to open pattern file.");
+    if (start_offset && fseeko(f_, (off_t)start_offset, SEEK_SET) != 0) throw std::runtime_error("Unable to seek in the pattern file.");
     findNextMarker();
 }
 ReadReader::~ReadReader() { if (f_ && f_ != stdin) fclose(f_); }

@@ -19,7 +19,9 @@ struct ReadBlock {
 
 class ReadReader {
 public:
-    ReadReader(const std::string &filename, bool fastq, int qualityOffset);
+    // start_offset / first_id: begin at a byte offset of the file that is the start of record number first_id (the host
+    // reader taking over from the device parser in the middle of a file)
+    ReadReader(const std::string &filename, bool fastq, int qualityOffset, uint64_t start_offset = 0, uint64_t first_id = 0);
     ~ReadReader();
     // up to max_reads reads; returns the number read (0 at end of file)
     uint64_t fillBlock(ReadBlock &b, uint64_t max_reads, bool want_ids);

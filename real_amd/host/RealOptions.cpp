@@ -30,7 +30,9 @@ void RealOptions::printHelp() const
               << "-filter_level <0..4, default=2>\n-similarity -err -trans -gc -gcmut_bias <scoring parameters>\n"
               << "-device <first HIP device, default=0>\n-gpus <number of devices, default=1>\n"
               << "-index <device|host, where the signature lists are sorted, default=device>\n"
-              << "-block <positions per index block, default=as many as fit>\n-batch <reads per device batch>\n";
+              << "-block <positions per index block, default=as many as fit>\n-batch <reads per device batch>\n"
+              << "-gpuparse <parse the read file on the device, default=1>\n-chunk <bytes of read-file text per device call, default=268435456>\n"
+              << "Reads longer than " << 256 << " bases are refused (the reference has no such limit).\n";
 }
 
 // The hand-rolled argv loop of RealOptions.cpp:140-396: "-x value" pairs, unknown arguments are
@@ -79,6 +81,7 @@ RealOptions::RealOptions(int argc, char *argv[])
         else if (a == "-batch") { batch_reads = strtoull(need("-batch").c_str(), 0, 10); i += 2; }
         else if (a == "-prefix_bits") { prefix_bits = atoi(need("-prefix_bits").c_str()); i += 2; }
         else if (a == "-gpuparse") { gpuparse = atoi(need("-gpuparse").c_str()); i += 2; }
+        else if (a == "-chunk") { chunk_bytes = strtoull(need("-chunk").c_str(), 0, 10); i += 2; }
         else if (a == "-table_kind") { table_kind = atoi(need("-table_kind").c_str()); i += 2; }
         else if (a == "-h") { printHelp(); i += 1; }
         else { std::cerr << "Ignoring unknown argument " << a << std::endl; i += 1; }
@@ -107,4 +110,6 @@ RealOptions::RealOptions(int argc, char *argv[])
     filter_mult /= 70.0;
     std::cerr << "filter_mult=" << filter_mult << std::endl;
     if (gpus < 1) gpus = 1;
+    if (chunk_bytes < 4096) chunk_bytes = 4096;
+    if (chunk_bytes > (4ull << 30) - (1ull << 20)) chunk_bytes = (4ull << 30) - (1ull << 20); // real_hip_parse_reads: n_bytes < 4 GiB
 }

@@ -30,6 +30,7 @@ struct RealOptions {
     unsigned prefix_bits = 0;
     unsigned table_kind = 0;         // -table_kind: device bucket tables (real_hip.h), 0 = auto
     unsigned gpuparse = 1;           // -gpuparse: parse the read file on the device when it is in one-line-per-field form
+    uint64_t chunk_bytes = 256ull << 20; // -chunk: bytes of read-file text handed to a device at a time (< 4 GiB)
 
     RealOptions() {}
     RealOptions(int argc, char *argv[]); // throws std::runtime_error like the reference

@@ -8,15 +8,24 @@
 // (matchAllImplementation.cpp:359-538) by calls into libreal_hip.so.  Loop structure as in the
 // reference: genome files -> index blocks -> all reads re-streamed per block -> output.
 //
+// The read file travels as text: chunks of whole records are read into pinned buffers by a prefetch
+// thread, parsed and matched on the device(s) (real_hip_parse_reads + real_hip_match_unique), and in the
+// output pass parsed again for the id / sequence spans, from which the host formats the lines with all
+// its cores and writes them with large sequential writes.  A file (or a later part of one) that is not in
+// one-line-per-field form is read by the host reader from that record on.
+//
 // Deliberate differences from reference quirks (SURVEY 8a "quirks"): matchAll handles FASTQ input
 // (quirk 1) and writes every line (quirk 2); the exit status is non-zero on errors (quirk 6).
+#include <omp.h>
+
 #include <cfloat>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <iostream>
 #include <memory>
-#include <sstream>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -30,10 +39,24 @@
 
 namespace {
 
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// where the wall time went; printed as one "timing:" line on stderr at the end (bench_support/cli_midsize.py reads it)
+struct Timers {
+    double genome = 0, index = 0, read = 0, parse = 0, match = 0, format = 0, write = 0, total = 0;
+    uint64_t reads = 0, lines = 0, out_bytes = 0;
+    void print() const
+    {
+        fprintf(stderr, "timing: genome_load_s=%.3f index_s=%.3f read_file_s=%.3f parse_s=%.3f match_s=%.3f format_s=%.3f write_s=%.3f total_s=%.3f reads=%llu lines=%llu out_bytes=%llu\n",
+                genome, index, read, parse, match, format, write, total, (unsigned long long)reads, (unsigned long long)lines, (unsigned long long)out_bytes);
+    }
+};
+
 struct Ctx {
     real_hip_ctx *h = nullptr;
     ~Ctx() { if (h) real_hip_destroy(h); }
 };
+typedef std::vector<std::unique_ptr<Ctx>> CtxVec;
 
 void check(real_hip_ctx *h, int rc, const char *what)
 {
@@ -44,7 +67,7 @@ void check(real_hip_ctx *h, int rc, const char *what)
     throw std::runtime_error(msg);
 }
 
-std::vector<std::unique_ptr<Ctx>> makeContexts(const RealOptions &o)
+CtxVec makeContexts(const RealOptions &o)
 {
     real_hip_params p;
     memset(&p, 0, sizeof p);
@@ -52,7 +75,7 @@ std::vector<std::unique_ptr<Ctx>> makeContexts(const RealOptions &o)
     p.seedl = o.seedl; p.seedkmax = o.seedkmax; p.totalkmax = o.totalkmax; p.scores = o.scores;
     p.prefix_bits = o.prefix_bits; p.table_kind = o.table_kind; p.filter_mult = o.filter_mult;
     real_hip_scoring_table(o.similarity, o.gc, o.trans, o.err, o.gcmut_bias, p.LL); // Scoring(opts...) :1115
-    std::vector<std::unique_ptr<Ctx>> v;
+    CtxVec v;
     for (int g = 0; g < o.gpus; ++g) {
         p.device = o.device + g;
         std::unique_ptr<Ctx> c(new Ctx);
@@ -62,8 +85,25 @@ std::vector<std::unique_ptr<Ctx>> makeContexts(const RealOptions &o)
     return v;
 }
 
-// positions per index block from the HBM budget: 6 x 8 B entries + 16 B sort workspace per window,
-// bucket tables on top (the device-side analogue of matchUniqueImplementation.cpp:1221-1244)
+// run f(g) for g in [0, n) on one host thread per context; the first exception is rethrown
+template <class F>
+void onEach(size_t n, F f)
+{
+    if (n == 1) { f((size_t)0); return; }
+    std::vector<std::thread> th;
+    std::vector<std::string> errs(n);
+    std::vector<int> nomem(n, 0);
+    for (size_t g = 0; g < n; ++g)
+        th.emplace_back([&, g]() {
+            try { f(g); } catch (const std::bad_alloc &) { nomem[g] = 1; } catch (const std::exception &e) { errs[g] = e.what(); if (errs[g].empty()) errs[g] = "error"; }
+        });
+    for (auto &t : th) t.join();
+    for (size_t g = 0; g < n; ++g) if (nomem[g]) throw std::bad_alloc();
+    for (auto &e : errs) if (!e.empty()) throw std::runtime_error(e);
+}
+
+// positions per index block from the HBM budget: the tables of a block plus the transients of its build
+// (the device-side analogue of matchUniqueImplementation.cpp:1221-1244)
 uint64_t blockEntries(const RealOptions &o, real_hip_ctx *h, uint64_t windows)
 {
     if (o.block_entries) return o.block_entries;
@@ -75,26 +115,74 @@ uint64_t blockEntries(const RealOptions &o, real_hip_ctx *h, uint64_t windows)
     return windows < cap ? windows : cap;
 }
 
-char remapChar(uint8_t c) { return c < 4 ? "ACGT"[c] : 'N'; } // acgtnMap.hpp:24-35
-
-std::string readString(const uint8_t *m, uint64_t n, bool inverted)
-{
-    std::string s((size_t)n, 'N');
-    if (!inverted) for (uint64_t i = 0; i < n; ++i) s[i] = remapChar(m[i]);
-    else for (uint64_t i = 0; i < n; ++i) { uint8_t c = m[n - 1 - i]; s[i] = remapChar(c < 4 ? 3 - c : 4); } // transposed
-    return s;
-}
-
 struct Ranges { std::vector<std::vector<std::string>> names; std::vector<std::vector<uint64_t>> starts; };
 
-// one output line; columns as printMatchUnlocked
-void formatLine(std::ostringstream &out, const std::string &id, const std::string &seq, bool scores, float score, uint64_t patl,
-                bool inverted, const std::string &fragname, uint64_t pos1, unsigned errors)
+// ---- output lines (printMatchUnlocked, matchUniqueImplementation.cpp:252-321) --------------------------
+// id \t sequence as matched \t score|"" \t 1 \t a \t patl \t +|- \t fragment name \t 1-based position \t "" \t errors \n
+inline void appendTail(std::string &out, bool scores, float score, uint64_t patl, bool inverted, const std::string &fragname, uint64_t pos1,
+                       unsigned errors)
 {
-    out << id << "\t" << seq << "\t";
-    if (scores) out << score;
-    out << "\t" << 1 << "\t" << "a" << "\t" << patl << "\t" << (inverted ? "-" : "+") << "\t" << fragname << "\t" << pos1 << "\t"
-        << "\t" << errors << "\n";
+    char buf[96];
+    out.push_back('\t');
+    if (scores) out.append(buf, (size_t)snprintf(buf, sizeof buf, "%g", (double)score)); // operator<<(float): %g, six digits
+    out.append(buf, (size_t)snprintf(buf, sizeof buf, "\t1\ta\t%llu\t%c\t", (unsigned long long)patl, inverted ? '-' : '+'));
+    out.append(fragname);
+    out.append(buf, (size_t)snprintf(buf, sizeof buf, "\t%llu\t\t%u\n", (unsigned long long)pos1, errors));
+}
+// the sequence column from mapped symbols: remapChar (acgtnMap.hpp:24-35) of the pattern, or of its transposed form
+inline void appendSeqMapped(std::string &out, const uint8_t *m, uint64_t n, bool inverted)
+{
+    const size_t at = out.size();
+    out.resize(at + n);
+    char *d = &out[at];
+    if (!inverted) for (uint64_t i = 0; i < n; ++i) d[i] = m[i] < 4 ? "ACGT"[m[i]] : 'N';
+    else for (uint64_t i = 0; i < n; ++i) { const uint8_t c = m[n - 1 - i]; d[i] = c < 4 ? "TGCA"[c] : 'N'; }
+}
+// ... or straight from the characters of the read file (same mapping: anything but ACGT, lowercase too, prints as N)
+inline void appendSeqText(std::string &out, const char *t, uint64_t n, bool inverted)
+{
+    const size_t at = out.size();
+    out.resize(at + n);
+    char *d = &out[at];
+    if (!inverted)
+        for (uint64_t i = 0; i < n; ++i) { const char c = t[i]; d[i] = (c == 'A' || c == 'C' || c == 'G' || c == 'T') ? c : 'N'; }
+    else
+        for (uint64_t i = 0; i < n; ++i) {
+            const char c = t[n - 1 - i];
+            d[i] = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N';
+        }
+}
+
+struct Record { unsigned st, frag, errors, file; uint64_t pos; };
+inline Record unpack(uint64_t rec)
+{
+    Record r;
+    r.st = (unsigned)(rec >> 61); r.frag = (rec >> 45) & 0xffff; r.errors = (rec >> 41) & 15; r.file = (rec >> 35) & 63; r.pos = rec & ((1ull << 35) - 1);
+    return r;
+}
+
+// The lines of reads [0, n) of one block, formatted by all host threads (each a contiguous range of reads into its
+// own buffer) and written in read order with one large write per buffer.  line(i, out) appends read i's line(s).
+template <class LineFn>
+void formatAndWrite(uint64_t n, FILE *out, Timers &T, LineFn line)
+{
+    const int nt = std::max(1, omp_get_max_threads());
+    std::vector<std::string> buf((size_t)nt);
+    const double t0 = now_s();
+#pragma omp parallel num_threads(nt)
+    {
+        const int t = omp_get_thread_num();
+        const uint64_t lo = n * (uint64_t)t / nt, hi = n * (uint64_t)(t + 1) / nt;
+        std::string &b = buf[(size_t)t];
+        b.reserve((size_t)(hi - lo) * 64);
+        for (uint64_t i = lo; i < hi; ++i) line(i, b);
+    }
+    const double t1 = now_s();
+    for (auto &b : buf) {
+        if (!b.empty() && fwrite(b.data(), 1, b.size(), out) != b.size()) throw std::runtime_error("write to the output file failed");
+        T.out_bytes += b.size();
+    }
+    T.format += t1 - t0; T.write += now_s() - t1;
 }
 
 // text + one index block on every device
@@ -104,21 +192,22 @@ struct Resident {
     std::vector<uint64_t> text2bit, wildbits;
 };
 
-void setText(const RealOptions &o, std::vector<std::unique_ptr<Ctx>> &ctx, Resident &R, unsigned fi)
+void setText(const RealOptions &o, CtxVec &ctx, Resident &R, unsigned fi)
 {
     if (o.host_index) { R.G.pack(R.text2bit, R.wildbits); enumerateWindows(R.G.sym, o.seedl, R.wpos); }
-    for (auto &c : ctx) {
+    onEach(ctx.size(), [&](size_t g) {
+        real_hip_ctx *h = ctx[g]->h;
         if (o.host_index)
-            check(c->h, real_hip_set_text(c->h, fi, R.text2bit.data(), R.wildbits.data(), R.G.sym.size(), R.G.frag_start.data(),
-                                          (uint32_t)R.G.frag_names.size()), "real_hip_set_text");
+            check(h, real_hip_set_text(h, fi, R.text2bit.data(), R.wildbits.data(), R.G.sym.size(), R.G.frag_start.data(),
+                                       (uint32_t)R.G.frag_names.size()), "real_hip_set_text");
         else
-            check(c->h, real_hip_set_text_symbols(c->h, fi, R.G.sym.data(), R.G.sym.size(), 0, R.G.frag_start.data(),
-                                                  (uint32_t)R.G.frag_names.size()), "real_hip_set_text_symbols");
-    }
+            check(h, real_hip_set_text_symbols(h, fi, R.G.sym.data(), R.G.sym.size(), 0, R.G.frag_start.data(),
+                                               (uint32_t)R.G.frag_names.size()), "real_hip_set_text_symbols");
+    });
 }
 
 // returns entries of the block, sets have_next
-uint64_t nextBlock(const RealOptions &o, std::vector<std::unique_ptr<Ctx>> &ctx, Resident &R, uint64_t first, uint64_t n_list, bool &have_next)
+uint64_t nextBlock(const RealOptions &o, CtxVec &ctx, Resident &R, uint64_t first, uint64_t n_list, bool &have_next)
 {
     uint64_t n = 0;
     if (o.host_index) {
@@ -126,54 +215,113 @@ uint64_t nextBlock(const RealOptions &o, std::vector<std::unique_ptr<Ctx>> &ctx,
         buildHostIndexBlock(R.G.sym, R.wpos, o.seedl, first, n_list, (int)o.sort_threads, B);
         const void *sg[6]; const uint32_t *ps[6];
         for (int k = 0; k < 6; ++k) { sg[k] = B.sign_ptr(k); ps[k] = B.pos[k].data(); }
-        for (auto &c : ctx) check(c->h, real_hip_set_index_block(c->h, B.n, sg, ps), "real_hip_set_index_block");
+        onEach(ctx.size(), [&](size_t g) { check(ctx[g]->h, real_hip_set_index_block(ctx[g]->h, B.n, sg, ps), "real_hip_set_index_block"); });
         n = B.n; have_next = B.have_next;
     } else {
-        for (auto &c : ctx) {
-            int hn = 0;
-            check(c->h, real_hip_build_index_block(c->h, first, n_list, &n, &hn), "real_hip_build_index_block");
-            have_next = hn != 0;
-        }
+        std::vector<uint64_t> ns(ctx.size(), 0);
+        std::vector<int> hn(ctx.size(), 0);
+        onEach(ctx.size(), [&](size_t g) {
+            check(ctx[g]->h, real_hip_build_index_block(ctx[g]->h, first, n_list, &ns[g], &hn[g]), "real_hip_build_index_block");
+        });
+        n = ns[0]; have_next = hn[0] != 0;
     }
     std::cerr << "Obtained " << n << " fragments of size " << o.seedl << std::endl; // ListSetBlockReader.hpp:36
     return n;
 }
 
-// The read file as raw text, cut into chunks of whole records for real_hip_parse_reads: a chunk ends behind a
-// newline whose index is a multiple of the lines per record (4 FASTQ, 2 FASTA); only text in that form parses.
+// ---- the read file as text chunks ----------------------------------------------------------------------
+// Chunks of whole records for real_hip_parse_reads: a chunk ends behind a newline whose index is a multiple of the
+// lines per record (4 FASTQ, 2 FASTA) -- only text in one-line-per-field form parses, and only for such text the cuts
+// are record boundaries.  Buffers are pinned (real_hip_host_alloc): they cross PCIe by DMA.  The next chunk is read by
+// a prefetch thread while the devices work on the current ones.
+struct Chunk {
+    char *text = nullptr;
+    size_t cap = 0, size = 0;
+    uint64_t file_offset = 0; // of text[0]
+};
+
 class RawChunker {
 public:
-    RawChunker(const std::string &fn, bool fastq, size_t chunk_bytes) : lpr_(fastq ? 4 : 2), cap_(chunk_bytes)
+    RawChunker(const std::string &fn, bool fastq, size_t chunk_bytes, size_t n_buffers) : lpr_(fastq ? 4 : 2)
     {
         f_ = fopen(fn.c_str(), "rb");
         if (!f_) throw std::runtime_error("Unable to open pattern file.");
+        for (size_t i = 0; i < n_buffers; ++i) {
+            Chunk c;
+            c.text = (char *)real_hip_host_alloc(chunk_bytes);
+            if (!c.text) throw std::bad_alloc();
+            c.cap = chunk_bytes;
+            pool_.push_back(c);
+            free_.push_back((int)i);
+        }
+        prefetch();
     }
-    ~RawChunker() { if (f_) fclose(f_); }
-    // false at the end of the file; text = whole records
-    bool next(std::vector<char> &text)
+    ~RawChunker()
     {
-        text.swap(carry_);
-        carry_.clear();
-        const size_t have = text.size();
-        text.resize(cap_);
-        size_t got = eof_ ? 0 : fread(text.data() + have, 1, cap_ - have, f_);
-        if (have + got < cap_) eof_ = true;
-        text.resize(have + got);
-        if (text.empty()) return false;
-        if (eof_) return true; // the rest of the file (the parser accepts a last line without newline)
-        size_t lines = 0, cut = 0;
-        for (const char *p = text.data(), *e = p + text.size(); (p = (const char *)memchr(p, '\n', e - p)); ++p)
-            if (++lines % lpr_ == 0) cut = (size_t)(p - text.data()) + 1;
-        if (!cut) throw std::runtime_error("a read record longer than the text chunk");
-        carry_.assign(text.begin() + cut, text.end());
-        text.resize(cut);
+        if (next_.valid()) next_.wait();
+        for (auto &c : pool_) real_hip_host_free(c.text);
+        if (f_) fclose(f_);
+    }
+    // the next chunk (the caller's until it hands it back with release); false at the end of the file
+    bool next(Chunk &out, double &wait_s)
+    {
+        if (!next_.valid()) prefetch();
+        if (!next_.valid()) return false;
+        const double t0 = now_s();
+        const int got = next_.get(); // (an exception of the reader thread surfaces here)
+        wait_s += now_s() - t0;
+        if (got < 0) { done_ = true; return false; }
+        out = pool_[(size_t)got];
+        prefetch();
         return true;
     }
+    void release(const Chunk &c)
+    {
+        for (size_t i = 0; i < pool_.size(); ++i)
+            if (pool_[i].text == c.text) free_.push_back((int)i);
+        prefetch();
+    }
 private:
+    // (only the thread that owns the chunker calls this, and only while no read is in flight: the reader thread is the
+    // only one that touches the file state then)
+    void prefetch()
+    {
+        if (done_ || next_.valid() || free_.empty()) return;
+        const int id = free_.back();
+        free_.pop_back();
+        next_ = std::async(std::launch::async, [this, id]() { return fill(id) ? id : -1; });
+    }
+    bool fill(int id)
+    {
+        Chunk &c = pool_[(size_t)id];
+        const size_t have = carry_.size();
+        if (have > c.cap) throw std::runtime_error("a read record longer than the text chunk");
+        if (have) memcpy(c.text, carry_.data(), have);
+        c.file_offset = offset_;
+        carry_.clear();
+        const size_t got = eof_ ? 0 : fread(c.text + have, 1, c.cap - have, f_);
+        if (have + got < c.cap) eof_ = true;
+        c.size = have + got;
+        if (!c.size) return false;
+        if (!eof_) {
+            size_t lines = 0, cut = 0;
+            for (const char *p = c.text, *e = p + c.size; (p = (const char *)memchr(p, '\n', (size_t)(e - p))); ++p)
+                if (++lines % lpr_ == 0) cut = (size_t)(p - c.text) + 1;
+            if (!cut) throw std::runtime_error("a read record longer than the text chunk");
+            carry_.assign(c.text + cut, c.text + c.size);
+            c.size = cut;
+        }
+        offset_ += c.size;
+        return true;
+    }
     FILE *f_ = nullptr;
-    size_t lpr_, cap_;
-    bool eof_ = false;
+    size_t lpr_;
+    bool eof_ = false, done_ = false;
+    uint64_t offset_ = 0;
     std::vector<char> carry_;
+    std::vector<Chunk> pool_;
+    std::vector<int> free_;
+    std::future<int> next_;
 };
 
 real_hip_batch makeBatch(const ReadBlock &b)
@@ -184,115 +332,153 @@ real_hip_batch makeBatch(const ReadBlock &b)
     rb.bases = b.bases.data(); rb.qual = b.qual.data(); rb.offsets = b.offsets.data();
     return rb;
 }
+real_hip_batch makeBatch(const real_hip_parsed &p)
+{
+    real_hip_batch rb;
+    memset(&rb, 0, sizeof rb);
+    rb.struct_size = sizeof rb; rb.on_device = 2; rb.n_reads = p.n_reads;
+    rb.bases = p.bases; rb.qual = p.qual; rb.offsets = p.offsets; rb.max_patl = p.max_patl;
+    return rb;
+}
+
+// One pass over the read file.  Rounds of up to one chunk per context: parsed on the devices, then onChunks(first_id,
+// chunks, parsed) sees them (in file order).  From the first chunk a device parser refuses (text not in one-line-per-
+// field form) the host reader takes over at that record: onBlocks(blocks) sees rounds of host-parsed blocks.  A file
+// that is refused from its first chunk on -- or -gpuparse 0 -- is read by the host reader alone.
+// Returns the number of reads seen.
+template <class OnChunks, class OnBlocks>
+uint64_t streamReads(const RealOptions &o, CtxVec &ctx, int qoff, bool want_ids, Timers &T, OnChunks onChunks, OnBlocks onBlocks)
+{
+    uint64_t next_id = 0, takeover_at = 0;
+    bool host = !o.gpuparse;
+    if (!host) {
+        RawChunker rc(o.patternfilename, o.fastq, o.chunk_bytes, 2 * ctx.size());
+        while (!host) {
+            std::vector<Chunk> ch;
+            for (size_t g = 0; g < ctx.size(); ++g) {
+                Chunk c;
+                if (!rc.next(c, T.read)) break;
+                ch.push_back(c);
+            }
+            if (ch.empty()) break;
+            std::vector<real_hip_parsed> pr(ch.size());
+            std::vector<int> prc(ch.size(), 0);
+            const double t0 = now_s();
+            onEach(ch.size(), [&](size_t g) {
+                prc[g] = real_hip_parse_reads(ctx[g]->h, ch[g].text, ch[g].size, 0, o.fastq ? 1 : 0, qoff, &pr[g]);
+            });
+            T.parse += now_s() - t0;
+            size_t good = 0;
+            for (; good < ch.size(); ++good) {
+                if (prc[good] == REAL_HIP_E_UNSUPPORTED) break;
+                check(ctx[good]->h, prc[good], "real_hip_parse_reads");
+            }
+            if (good < ch.size()) { host = true; takeover_at = ch[good].file_offset; }
+            ch.resize(good); pr.resize(good);
+            if (good) {
+                std::vector<uint64_t> first(good);
+                for (size_t g = 0; g < good; ++g) { first[g] = next_id; next_id += pr[g].n_reads; }
+                onChunks(first, ch, pr);
+            }
+            for (auto &c : ch) rc.release(c);
+        }
+        if (host) std::cerr << "read file leaves the one-line-per-field form at byte " << takeover_at << ": the host reader takes over from there" << std::endl;
+    }
+    if (host) {
+        ReadReader rr(o.patternfilename, o.fastq, qoff, takeover_at, next_id); // the whole read set is re-streamed per block, :1260
+        std::vector<ReadBlock> blk(ctx.size());
+        while (true) {
+            size_t used = 0;
+            const double t0 = now_s();
+            for (; used < ctx.size(); ++used)
+                if (!rr.fillBlock(blk[used], o.batch_reads, want_ids)) break;
+            T.parse += now_s() - t0;
+            if (!used) break;
+            onBlocks(blk, used);
+            for (size_t g = 0; g < used; ++g) next_id += blk[g].size();
+        }
+    }
+    return next_id;
+}
+
+void progress(uint64_t handled, uint64_t numpat)
+{
+    std::cerr << "\r                                                              \r" << (double)handled / (numpat ? numpat : 1) << std::flush;
+}
 
 // ---- EnumerateUniqueMatches::doMatching -------------------------------------------------
 int matchUnique(const RealOptions &o)
 {
-    const uint64_t numpat = ReadReader::countPatterns(o.patternfilename, o.fastq); // :1094
-    std::cerr << "number of reads " << numpat << std::endl;
+    Timers T;
+    const double t_begin = now_s();
     int qoff = o.fastq ? (o.qualityOffset ? (int)o.qualityOffset : ReadReader::getOffset(o.patternfilename)) : 0;
     if (o.fastq && !qoff) throw std::runtime_error("Unable to automatically detect FastQ quality format."); // :1112
-    std::vector<uint64_t> info(numpat, 0);                     // uniqueinfo(numpat), :1097
-    std::vector<float> score(o.scores ? numpat : 0, -FLT_MAX); // UniqueMatchInfo.hpp:191
+    // uniqueinfo(numpat), :1094-1097.  The reference counts the reads in a pass of its own; here the arrays grow with the
+    // first pass over the file (records start as NoMatch / -FLT_MAX, UniqueMatchInfo.hpp:191).
+    std::vector<uint64_t> info;
+    std::vector<float> score;
+    uint64_t numpat = 0;
+    bool counted = false;
+    auto grow = [&](uint64_t n) {
+        if (n > info.size()) {
+            const uint64_t to = std::max<uint64_t>(n, info.size() + info.size() / 2);
+            info.resize(to, 0);
+            if (o.scores) score.resize(to, -FLT_MAX);
+        }
+    };
     std::vector<std::string> files;
     getFileList(o.textfilename, files);
     if (files.empty()) throw std::runtime_error("no .fa text file found at " + o.textfilename);
     if (files.size() > 64) throw std::runtime_error("more than 64 text files (6 bits of file id, UniqueMatchInfo.hpp:31)");
-    auto ctx = makeContexts(o);
+    CtxVec ctx = makeContexts(o);
     Ranges RS;
     for (unsigned fi = 0; fi < files.size(); ++fi) {
         std::cerr << "Processing file " << files[fi] << ((fi + 1 == files.size()) ? " (last processed file)" : "") << std::endl;
         Resident R;
+        double t0 = now_s();
         R.G.load(files[fi]);
+        T.genome += now_s() - t0;
         RS.names.push_back(R.G.frag_names); RS.starts.push_back(R.G.frag_start);
+        t0 = now_s();
         setText(o, ctx, R, fi);
+        T.index += now_s() - t0;
         const uint64_t nwin_upper = R.G.sym.size();
         const uint64_t n_list = blockEntries(o, ctx[0]->h, nwin_upper ? nwin_upper : 1);
         uint64_t first = 0;
         bool have_next = true;
         while (have_next) {
+            t0 = now_s();
             const uint64_t n = nextBlock(o, ctx, R, first, n_list, have_next);
+            T.index += now_s() - t0;
             if (!n) break;
             first += n;
-            uint64_t handled = 0;
-            bool parsed_on_device = false;
-            if (o.gpuparse) {
-                // f2: the file goes to the device as text; one chunk per context and round.  Text that is not in
-                // one-line-per-field form is refused by the library and read by the host reader below.
-                RawChunker rc(o.patternfilename, o.fastq, (size_t)256 << 20);
-                std::vector<std::vector<char>> txt(ctx.size());
-                uint64_t next_id = 0;
-                parsed_on_device = true;
-                while (parsed_on_device) {
-                    size_t used = 0;
-                    for (; used < ctx.size(); ++used)
-                        if (!rc.next(txt[used])) break;
-                    if (!used) break;
-                    std::vector<real_hip_parsed> pr(used);
-                    std::vector<int> prc(used, 0);
-                    {
-                        std::vector<std::thread> th;
-                        for (size_t g = 0; g < used; ++g)
-                            th.emplace_back([&, g]() {
-                                prc[g] = real_hip_parse_reads(ctx[g]->h, txt[g].data(), txt[g].size(), 0, o.fastq ? 1 : 0, qoff, &pr[g]);
-                            });
-                        for (auto &t : th) t.join();
-                    }
-                    for (size_t g = 0; g < used; ++g) {
-                        if (prc[g] == REAL_HIP_E_UNSUPPORTED && handled == 0) { parsed_on_device = false; break; }
-                        check(ctx[g]->h, prc[g], "real_hip_parse_reads");
-                    }
-                    if (!parsed_on_device) break;
-                    std::vector<uint64_t> first(used);
-                    for (size_t g = 0; g < used; ++g) { first[g] = next_id; next_id += pr[g].n_reads; }
-                    if (next_id > numpat) throw std::runtime_error("device parser found more reads than countPatterns");
-                    std::vector<std::thread> th;
-                    std::vector<std::string> errs(used);
-                    for (size_t g = 0; g < used; ++g)
-                        th.emplace_back([&, g]() {
-                            try {
-                                real_hip_batch rb;
-                                memset(&rb, 0, sizeof rb);
-                                rb.struct_size = sizeof rb; rb.on_device = 2; rb.n_reads = pr[g].n_reads;
-                                rb.bases = pr[g].bases; rb.qual = pr[g].qual; rb.offsets = pr[g].offsets; rb.max_patl = pr[g].max_patl;
-                                if (rb.n_reads)
-                                    check(ctx[g]->h, real_hip_match_unique(ctx[g]->h, &rb, info.data() + first[g],
-                                                                           o.scores ? score.data() + first[g] : nullptr),
-                                          "real_hip_match_unique");
-                            } catch (const std::exception &e) { errs[g] = e.what(); }
-                        });
-                    for (auto &t : th) t.join();
-                    for (auto &e : errs) if (!e.empty()) throw std::runtime_error(e);
-                    handled = next_id;
-                    std::cerr << "\r                                                              \r" << (double)handled / (numpat ? numpat : 1) << std::flush;
-                }
-                if (parsed_on_device && handled != numpat) throw std::runtime_error("device parser and countPatterns disagree on the number of reads");
-            }
-            if (!parsed_on_device) {
-            ReadReader rr(o.patternfilename, o.fastq, qoff);     // the whole read set is re-streamed per block, :1260
-            std::vector<ReadBlock> blk(ctx.size());
-            while (true) {
-                size_t used = 0;
-                for (; used < ctx.size(); ++used)
-                    if (!rr.fillBlock(blk[used], o.batch_reads, false)) break;
-                if (!used) break;
-                std::vector<std::thread> th;
-                std::vector<std::string> errs(used);
-                for (size_t g = 0; g < used; ++g)
-                    th.emplace_back([&, g]() {
-                        try {
-                            real_hip_batch rb = makeBatch(blk[g]);
-                            check(ctx[g]->h, real_hip_match_unique(ctx[g]->h, &rb, info.data() + blk[g].first_id,
-                                                                   o.scores ? score.data() + blk[g].first_id : nullptr),
+            const uint64_t seen = streamReads(o, ctx, qoff, false, T,
+                [&](const std::vector<uint64_t> &first_id, const std::vector<Chunk> &ch, const std::vector<real_hip_parsed> &pr) {
+                    grow(first_id.back() + pr.back().n_reads);
+                    const double tm = now_s();
+                    onEach(ch.size(), [&](size_t g) {
+                        real_hip_batch rb = makeBatch(pr[g]);
+                        if (rb.n_reads)
+                            check(ctx[g]->h, real_hip_match_unique(ctx[g]->h, &rb, info.data() + first_id[g], o.scores ? score.data() + first_id[g] : nullptr),
                                   "real_hip_match_unique");
-                        } catch (const std::exception &e) { errs[g] = e.what(); }
                     });
-                for (auto &t : th) t.join();
-                for (auto &e : errs) if (!e.empty()) throw std::runtime_error(e);
-                for (size_t g = 0; g < used; ++g) handled += blk[g].size();
-                std::cerr << "\r                                                              \r" << (double)handled / (numpat ? numpat : 1) << std::flush;
-            }
-            }
+                    T.match += now_s() - tm;
+                    if (counted) progress(first_id.back() + pr.back().n_reads, numpat);
+                },
+                [&](std::vector<ReadBlock> &blk, size_t used) {
+                    grow(blk[used - 1].first_id + blk[used - 1].size());
+                    const double tm = now_s();
+                    onEach(used, [&](size_t g) {
+                        real_hip_batch rb = makeBatch(blk[g]);
+                        if (rb.n_reads)
+                            check(ctx[g]->h, real_hip_match_unique(ctx[g]->h, &rb, info.data() + blk[g].first_id, o.scores ? score.data() + blk[g].first_id : nullptr),
+                                  "real_hip_match_unique");
+                    });
+                    T.match += now_s() - tm;
+                    if (counted) progress(blk[used - 1].first_id + blk[used - 1].size(), numpat);
+                });
+            if (!counted) { numpat = seen; counted = true; std::cerr << "number of reads " << numpat << std::endl; } // :1096
+            else if (seen != numpat) throw std::runtime_error("the read file changed between two passes");
             std::cerr << std::endl;
         }
     }
@@ -300,83 +486,151 @@ int matchUnique(const RealOptions &o)
     // output, in read order (PatternIdReader re-stream, :1438-1486)
     FILE *out = (o.outputfilename == "-") ? stdout : fopen(o.outputfilename.c_str(), "wb");
     if (!out) throw std::runtime_error("cannot open output file " + o.outputfilename);
-    ReadReader rr(o.patternfilename, o.fastq, qoff);
-    ReadBlock b;
+    std::vector<char> obuf((size_t)8 << 20);
+    setvbuf(out, obuf.data(), _IOFBF, obuf.size());
     uint64_t unique = 0;
-    while (rr.fillBlock(b, 1u << 16, true)) {
-        std::ostringstream os;
-        for (uint64_t i = 0; i < b.size(); ++i) {
-            const uint64_t rec = info[b.first_id + i];
-            const unsigned st = (unsigned)(rec >> 61);
-            if (st != 1 && st != 2) continue; // NoMatch / NonUnique / Gapped print nothing
-            const unsigned frag = (rec >> 45) & 0xffff, errors = (rec >> 41) & 15, file = (rec >> 35) & 63;
-            const uint64_t pos = rec & ((1ull << 35) - 1);
-            const uint64_t lo = b.offsets[i], patl = b.offsets[i + 1] - lo;
-            formatLine(os, b.ids[i], readString(&b.bases[lo], patl, st == 2), o.scores, o.scores ? score[b.first_id + i] : 0.f, patl,
-                       st == 2, RS.names[file][frag], pos - RS.starts[file][frag] + 1, errors);
-            unique++;
-        }
-        const std::string s = os.str();
-        fwrite(s.data(), 1, s.size(), out);
-    }
+    std::vector<uint32_t> id_start, id_len;
+    std::vector<uint64_t> off;
+    streamReads(o, ctx, qoff, true, T,
+        [&](const std::vector<uint64_t> &first_id, const std::vector<Chunk> &ch, const std::vector<real_hip_parsed> &pr) {
+            for (size_t g = 0; g < ch.size(); ++g) { // (in file order; the spans of one chunk at a time)
+                const uint64_t n = pr[g].n_reads;
+                if (!n) continue;
+                id_start.resize(n); id_len.resize(n); off.resize(n + 1);
+                const double td = now_s();
+                check(ctx[g]->h, real_hip_download(ctx[g]->h, pr[g].id_start, id_start.data(), n * 4), "real_hip_download");
+                check(ctx[g]->h, real_hip_download(ctx[g]->h, pr[g].id_len, id_len.data(), n * 4), "real_hip_download");
+                check(ctx[g]->h, real_hip_download(ctx[g]->h, pr[g].offsets, off.data(), (n + 1) * 8), "real_hip_download");
+                T.parse += now_s() - td;
+                const char *text = ch[g].text;
+                const uint64_t base = first_id[g];
+                std::vector<uint64_t> cnt((size_t)omp_get_max_threads() + 1, 0);
+                formatAndWrite(n, out, T, [&](uint64_t i, std::string &b) {
+                    const Record r = unpack(info[base + i]);
+                    if (r.st != 1 && r.st != 2) return; // NoMatch / NonUnique / Gapped print nothing
+                    // the id is everything behind the marker up to the newline (a '\r' in front of it included, as the
+                    // reference's reader keeps it); the sequence is the next line
+                    uint64_t il = id_len[i];
+                    if (text[id_start[i] + il] == '\r') il++;
+                    const uint64_t patl = off[i + 1] - off[i];
+                    b.append(text + id_start[i], il);
+                    b.push_back('\t');
+                    appendSeqText(b, text + id_start[i] + il + 1, patl, r.st == 2);
+                    appendTail(b, o.scores, o.scores ? score[base + i] : 0.f, patl, r.st == 2, RS.names[r.file][r.frag], r.pos - RS.starts[r.file][r.frag] + 1, r.errors);
+                    cnt[(size_t)omp_get_thread_num()]++;
+                });
+                for (uint64_t c : cnt) unique += c;
+            }
+        },
+        [&](std::vector<ReadBlock> &blk, size_t used) {
+            for (size_t g = 0; g < used; ++g) {
+                const ReadBlock &b = blk[g];
+                std::vector<uint64_t> cnt((size_t)omp_get_max_threads() + 1, 0);
+                formatAndWrite(b.size(), out, T, [&](uint64_t i, std::string &s) {
+                    const Record r = unpack(info[b.first_id + i]);
+                    if (r.st != 1 && r.st != 2) return;
+                    const uint64_t lo = b.offsets[i], patl = b.offsets[i + 1] - lo;
+                    s.append(b.ids[i]);
+                    s.push_back('\t');
+                    appendSeqMapped(s, &b.bases[lo], patl, r.st == 2);
+                    appendTail(s, o.scores, o.scores ? score[b.first_id + i] : 0.f, patl, r.st == 2, RS.names[r.file][r.frag], r.pos - RS.starts[r.file][r.frag] + 1, r.errors);
+                    cnt[(size_t)omp_get_thread_num()]++;
+                });
+                for (uint64_t c : cnt) unique += c;
+            }
+        });
+    if (fflush(out) != 0) throw std::runtime_error("write to the output file failed");
     if (out != stdout) fclose(out);
     std::cerr << "unique: " << unique << std::endl; // :1488
+    T.reads = numpat; T.lines = unique; T.total = now_s() - t_begin;
+    T.print();
     return EXIT_SUCCESS;
 }
 
 // ---- EnumerateAllMatches::doMatching ----------------------------------------------------
+// Hits are emitted per genome block (matchAllImplementation.cpp:451-535).  The read blocks of a round go to the
+// contexts in parallel; their lines are written in read order.
 int matchAll(const RealOptions &o)
 {
+    Timers T;
+    const double t_begin = now_s();
     int qoff = o.fastq ? (o.qualityOffset ? (int)o.qualityOffset : ReadReader::getOffset(o.patternfilename)) : 0;
     if (o.fastq && !qoff) throw std::runtime_error("Unable to automatically detect FastQ quality format.");
     std::vector<std::string> files;
     getFileList(o.textfilename, files);
     if (files.empty()) throw std::runtime_error("no .fa text file found at " + o.textfilename);
-    auto ctx = makeContexts(o);
+    CtxVec ctx = makeContexts(o);
     FILE *out = (o.outputfilename == "-") ? stdout : fopen(o.outputfilename.c_str(), "wb");
     if (!out) throw std::runtime_error("cannot open output file " + o.outputfilename);
+    std::vector<char> obuf((size_t)8 << 20);
+    setvbuf(out, obuf.data(), _IOFBF, obuf.size());
+    uint64_t n_reads = 0, n_lines = 0;
     for (unsigned fi = 0; fi < files.size(); ++fi) {
         std::cerr << "Processing file " << files[fi] << std::endl;
         Resident R;
+        double t0 = now_s();
         R.G.load(files[fi]);
+        T.genome += now_s() - t0;
+        t0 = now_s();
         setText(o, ctx, R, fi);
+        T.index += now_s() - t0;
         const uint64_t n_list = blockEntries(o, ctx[0]->h, R.G.sym.size() ? R.G.sym.size() : 1);
         uint64_t first = 0;
         bool have_next = true;
         while (have_next) {
+            t0 = now_s();
             const uint64_t n = nextBlock(o, ctx, R, first, n_list, have_next);
+            T.index += now_s() - t0;
             if (!n) break;
             first += n;
-            ReadReader rr(o.patternfilename, o.fastq, qoff); // hits are emitted per genome block, :451-535
-            ReadBlock b;
-            std::vector<real_hip_hit> hits(1u << 20);
-            std::vector<uint64_t> hoff;
-            while (rr.fillBlock(b, o.batch_reads, true)) {
-                real_hip_batch rb = makeBatch(b);
-                hoff.assign(b.size() + 1, 0);
-                uint64_t nh = 0;
-                int rc = real_hip_match_all(ctx[0]->h, &rb, hits.data(), hits.size(), &nh, hoff.data());
-                if (rc == REAL_HIP_E_OVERFLOW) { // retry with the size the library reports
-                    hits.resize(nh + 16);
-                    rc = real_hip_match_all(ctx[0]->h, &rb, hits.data(), hits.size(), &nh, hoff.data());
-                }
-                check(ctx[0]->h, rc, "real_hip_match_all");
-                std::ostringstream os;
-                for (uint64_t i = 0; i < b.size(); ++i) {
-                    const uint64_t lo = b.offsets[i], patl = b.offsets[i + 1] - lo;
-                    for (uint64_t k = hoff[i]; k < hoff[i + 1]; ++k) {
-                        const real_hip_hit &M = hits[k];
-                        formatLine(os, b.ids[i], readString(&b.bases[lo], patl, M.inverted), o.scores, M.score, patl, M.inverted,
-                                   R.G.frag_names[M.frag], (uint64_t)M.pos - R.G.frag_start[M.frag] + 1, M.k);
+            ReadReader rr(o.patternfilename, o.fastq, qoff);
+            std::vector<ReadBlock> blk(ctx.size());
+            std::vector<std::vector<real_hip_hit>> hits(ctx.size(), std::vector<real_hip_hit>(1u << 20));
+            std::vector<std::vector<uint64_t>> hoff(ctx.size());
+            n_reads = 0;
+            while (true) {
+                size_t used = 0;
+                t0 = now_s();
+                for (; used < ctx.size(); ++used)
+                    if (!rr.fillBlock(blk[used], o.batch_reads, true)) break;
+                T.parse += now_s() - t0;
+                if (!used) break;
+                t0 = now_s();
+                onEach(used, [&](size_t g) {
+                    real_hip_batch rb = makeBatch(blk[g]);
+                    hoff[g].assign(blk[g].size() + 1, 0);
+                    uint64_t nh = 0;
+                    int rc = real_hip_match_all(ctx[g]->h, &rb, hits[g].data(), hits[g].size(), &nh, hoff[g].data());
+                    if (rc == REAL_HIP_E_OVERFLOW) { // retry with the size the library reports
+                        hits[g].resize(nh + 16);
+                        rc = real_hip_match_all(ctx[g]->h, &rb, hits[g].data(), hits[g].size(), &nh, hoff[g].data());
                     }
+                    check(ctx[g]->h, rc, "real_hip_match_all");
+                });
+                T.match += now_s() - t0;
+                for (size_t g = 0; g < used; ++g) {
+                    const ReadBlock &b = blk[g];
+                    n_reads += b.size();
+                    n_lines += hoff[g][b.size()];
+                    formatAndWrite(b.size(), out, T, [&](uint64_t i, std::string &s) {
+                        const uint64_t lo = b.offsets[i], patl = b.offsets[i + 1] - lo;
+                        for (uint64_t k = hoff[g][i]; k < hoff[g][i + 1]; ++k) {
+                            const real_hip_hit &M = hits[g][k];
+                            s.append(b.ids[i]);
+                            s.push_back('\t');
+                            appendSeqMapped(s, &b.bases[lo], patl, M.inverted);
+                            appendTail(s, o.scores, M.score, patl, M.inverted, R.G.frag_names[M.frag], (uint64_t)M.pos - R.G.frag_start[M.frag] + 1, M.k);
+                        }
+                    });
                 }
-                const std::string s = os.str();
-                fwrite(s.data(), 1, s.size(), out);
             }
         }
     }
+    if (fflush(out) != 0) throw std::runtime_error("write to the output file failed");
     if (out != stdout) fclose(out);
     std::cerr << "All done." << std::endl;
+    T.reads = n_reads; T.lines = n_lines; T.total = now_s() - t_begin;
+    T.print();
     return EXIT_SUCCESS;
 }
 

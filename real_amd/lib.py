@@ -31,8 +31,9 @@ ABI_SYMBOLS = [
     "real_hip_scoring_table", "real_hip_create", "real_hip_destroy", "real_hip_strerror",
     "real_hip_last_error", "real_hip_abi_version", "real_hip_set_match_params", "real_hip_wait_event", "real_hip_device_memory", "real_hip_set_text", "real_hip_set_text_symbols",
     "real_hip_set_index_block", "real_hip_build_index_block", "real_hip_index_info", "real_hip_index_build_stats",
-    "real_hip_index_table_kind", "real_hip_index_download", "real_hip_index_export", "real_hip_match_unique", "real_hip_match_all",
-    "real_hip_parse_reads", "real_hip_counters_get", "real_hip_kernel_time", "real_hip_timing_enable",
+    "real_hip_index_table_kind", "real_hip_index_download", "real_hip_index_export", "real_hip_match_unique", "real_hip_match_all", "real_hip_match_unique_submit", "real_hip_wait",
+    "real_hip_host_alloc", "real_hip_host_free",
+    "real_hip_parse_reads", "real_hip_download", "real_hip_counters_get", "real_hip_kernel_time", "real_hip_timing_enable",
 ]
 
 
@@ -46,7 +47,8 @@ class RealHipParams(C.Structure):
 class RealHipBatch(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("on_device", C.c_uint32), ("n_reads", C.c_uint64),
                 ("bases", C.c_void_p), ("qual", C.c_void_p), ("offsets", C.c_void_p),
-                ("patl", C.c_uint32), ("max_patl", C.c_uint32)]
+                ("patl", C.c_uint32), ("max_patl", C.c_uint32),
+                ("packed", C.c_uint32), ("reserved", C.c_uint32), ("nflags", C.c_void_p)]
 
 
 class RealHipParsed(C.Structure):
@@ -114,9 +116,16 @@ def load():
     L.real_hip_index_info.argtypes = [vp, C.POINTER(u64), C.POINTER(u32)]
     L.real_hip_index_table_kind.argtypes = [vp, C.POINTER(u32)]
     L.real_hip_parse_reads.argtypes = [vp, vp, u64, C.c_int, C.c_int, C.c_int, C.POINTER(RealHipParsed)]
+    L.real_hip_download.argtypes = [vp, vp, vp, C.c_size_t]
     L.real_hip_index_download.argtypes = [vp, C.c_int, vp, vp]
     L.real_hip_index_export.argtypes = [vp, C.c_int, vp, vp]
     L.real_hip_match_unique.argtypes = [vp, C.POINTER(RealHipBatch), vp, vp]
+    L.real_hip_match_unique_submit.argtypes = [vp, C.POINTER(RealHipBatch), vp, vp, u32, C.c_int]
+    L.real_hip_wait.argtypes = [vp, u32]
+    L.real_hip_host_alloc.argtypes = [C.c_size_t]
+    L.real_hip_host_alloc.restype = vp
+    L.real_hip_host_free.argtypes = [vp]
+    L.real_hip_host_free.restype = None
     L.real_hip_match_all.argtypes = [vp, C.POINTER(RealHipBatch), vp, u64, C.POINTER(u64), vp]
     L.real_hip_counters_get.argtypes = [vp, C.POINTER(RealHipCounters), C.c_int]
     L.real_hip_kernel_time.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(u64), C.c_int]

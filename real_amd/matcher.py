@@ -152,6 +152,9 @@ class HipMatcher:
         if getattr(self, "_h", None):
             self._L.real_hip_destroy(self._h)
             self._h = None
+        for p in getattr(self, "_pinned", []):
+            self._L.real_hip_host_free(p)
+        self._pinned = []
 
     def __del__(self):
         self.close()
@@ -266,14 +269,18 @@ class HipMatcher:
         return b
 
     def match_unique(self, bases, qual, offsets=None, patl: int = 0, info=None, score=None,
-                     n_reads: Optional[int] = None, max_patl: int = 0):
+                     n_reads: Optional[int] = None, max_patl: int = 0, packed: bool = False, nflags=None):
         """UniqueMatcher::match over a pattern block, folding into info/score in place.
         Host numpy arrays or device torch tensors (all of one kind)."""
         if isinstance(bases, np.ndarray):
             bases = np.ascontiguousarray(bases, dtype=np.uint8)
             qual = None if qual is None else np.ascontiguousarray(qual, dtype=np.uint8)
             offsets = None if offsets is None else np.ascontiguousarray(offsets, dtype=np.uint64)
+        if packed and offsets is None and n_reads is None:
+            raise ValueError("a packed batch of uniform length needs n_reads")
         b = self._batch(bases, qual, offsets, patl, n_reads, max_patl)
+        b.packed = int(bool(packed))
+        b.nflags = _ptr(nflags)
         if info is None:
             info, score = new_unique_info(int(b.n_reads), self.opts.scores)
         self.sync_inputs(bases, qual, offsets, info, score)
@@ -298,6 +305,33 @@ class HipMatcher:
                 continue
             self._check(rc)
             return out[:int(nout.value)], hoff
+
+    # -- pipelined host batches (submit / wait over two slots) --
+    def host_alloc(self, shape, dtype) -> np.ndarray:
+        """a numpy array over pinned host memory (real_hip_host_alloc): batches handed over from it cross PCIe by DMA
+        without a staging copy, which is what makes submit asynchronous.  Freed with the matcher."""
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape))
+        p = self._L.real_hip_host_alloc(max(1, n * dt.itemsize))
+        if not p:
+            raise RealHipError(_lib.REAL_HIP_E_NOMEM, "real_hip_host_alloc")
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(p)
+        buf = (C.c_uint8 * (n * dt.itemsize)).from_address(p)
+        return np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
+
+    def submit_unique(self, slot: int, bases, qual, info, score, patl: int = 0, offsets=None, n_reads: Optional[int] = None,
+                      packed: bool = False, nflags=None, fresh: bool = False):
+        """real_hip_match_unique_submit: queue upload, kernels and download of one host batch; returns at once.  The
+        arrays must stay alive and untouched until wait(slot)."""
+        b = self._batch(bases, qual, offsets, patl, n_reads)
+        b.on_device = 0
+        b.packed = int(bool(packed))
+        b.nflags = _ptr(nflags)
+        self._check(self._L.real_hip_match_unique_submit(self._h, C.byref(b), _ptr(info), _ptr(score), slot, int(bool(fresh))))
+
+    def wait(self, slot: int):
+        self._check(self._L.real_hip_wait(self._h, slot))
 
     # -- read ingestion on the device --
     def parse_reads(self, text, fastq: bool, quality_offset: int = 33):
@@ -330,11 +364,7 @@ class HipMatcher:
         """copy `count` items of a device array the library returned to the host (tests, id strings)"""
         out = np.zeros(count, dtype=dtype)
         if count:
-            hip = C.CDLL("libamdhip64.so")
-            hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-            rc = hip.hipMemcpy(out.ctypes.data, C.c_void_p(int(dev_ptr)), out.nbytes, 2)    # hipMemcpyDeviceToHost
-            if rc != 0:
-                raise RuntimeError("hipMemcpy device->host failed: %d" % rc)
+            self._check(self._L.real_hip_download(self._h, C.c_void_p(int(dev_ptr)), out.ctypes.data, out.nbytes))
         return out
 
     # -- instrumentation --

@@ -167,3 +167,25 @@ def reads_to_fasta(b: ReadBatch, path: str) -> None:
             lo, hi = int(b.offsets[i]), int(b.offsets[i + 1])
             f.write(">" + (b.ids[i] if b.ids else "r%d" % i) + "\n")
             f.write("".join(ALPHABET[c] for c in b.bases[lo:hi]) + "\n")
+
+
+def pack_bases(bases: np.ndarray):
+    """mapped symbols (one per byte) -> the 2-bit packed form of a real_hip_batch with packed = 1: base g of the
+    concatenated batch at bits 7-2(g%4)-1.. of byte g/4.  Symbols > 3 cannot be packed (they are stored as 0); the
+    caller flags their reads in nflags."""
+    b = np.ascontiguousarray(bases, dtype=np.uint8)
+    pad = (-b.shape[0]) % 4
+    if pad:
+        b = np.concatenate([b, np.zeros(pad, dtype=np.uint8)])
+    q = (b & 3).reshape(-1, 4)
+    return ((q[:, 0] << 6) | (q[:, 1] << 4) | (q[:, 2] << 2) | q[:, 3]).astype(np.uint8)
+
+
+def read_nflags(bases: np.ndarray, offsets: np.ndarray) -> np.ndarray:
+    """bit (i%8) of byte i/8 set iff read i holds a symbol > 3"""
+    n = offsets.shape[0] - 1
+    bad = np.zeros(n, dtype=bool)
+    idx = np.nonzero(np.asarray(bases) > 3)[0]
+    if idx.size:
+        bad[np.searchsorted(offsets.astype(np.int64), idx, side="right") - 1] = True
+    return np.packbits(bad, bitorder="little")

@@ -119,3 +119,59 @@ def test_real_cli_errors_are_loud(tmp_path):
     r = subprocess.run([REAL, "-t", "/nonexistent.fa", "-p", "/nonexistent.fq", "-o", str(tmp_path / "o")],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
     assert r.returncode != 0
+
+
+@pytest.mark.parametrize("irregular", ["wrapped", "blank_line", "crlf"])
+def test_real_cli_irregular_record_beyond_the_first_chunk(ora, tmp_path, irregular):
+    """A read file that leaves the one-line-per-field form in its middle: the chunks in front of that record are parsed
+    on the device, from the refused chunk on the host reader takes over at the right record (small -chunk so that the
+    file is many chunks).  "crlf" stays on the device parser all the way; the '\\r' belongs to the id, as in the
+    reference (FastQReader.hpp:138-141 reads the id up to the newline)."""
+    g = synth.random_genome(80_000, seed=41, n_frag=3, n_runs=6, repeats=15)
+    b = synth.sample_reads(g, 1800, 100, 0.02, seed=44, n_read_prob=0.0005)
+    fa, rd = write_inputs(tmp_path, g, b, True)
+    lines = open(rd).read().split("\n")
+    assert len(lines) == 4 * 1800 + 1
+    ids = list(b.ids)
+    if irregular == "wrapped":                                     # record 900: sequence and quality over two lines each
+        s, q = lines[4 * 900 + 1], lines[4 * 900 + 3]
+        lines[4 * 900 + 1] = s[:41] + "\n" + s[41:]
+        lines[4 * 900 + 3] = q[:17] + "\n" + q[17:]
+    elif irregular == "blank_line":
+        lines[4 * 1200] = "\n" + lines[4 * 1200]                   # an empty line in front of record 1200
+    text = "\n".join(lines)
+    if irregular == "crlf":
+        text = text.replace("\n", "\r\n")
+        ids = [i + "\r" for i in ids]
+    open(rd, "w", newline="").write(text)
+    out = str(tmp_path / "out.tsv")
+    r = subprocess.run([REAL, "-t", fa, "-p", rd, "-o", out, "-e", "3", "-s", "2", "-l", "32", "-q", "1", "-chunk", "30000"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    took_over = "host reader takes over" in r.stderr.decode()
+    assert took_over == (irregular != "crlf"), r.stderr.decode()[-1500:]
+    info, score = oracle_unique(ora, g, b, 32, 2, 3, 1)
+    b2 = synth.ReadBatch(bases=b.bases, qual=b.qual, offsets=b.offsets, ids=ids)
+    want = expected_unique(ora, g, b2, info, score, 1)
+    got = open(out, newline="").read().split("\n")[:-1]
+    assert got == want
+
+
+def test_real_cli_known_answer_of_the_survey(tmp_path):
+    """SURVEY 4 "end-to-end observed": a 36-mer copied from 0-based genome offset 207 and reverse-complemented
+    (`p207_inv`) is reported '-', position 208, 0 errors, the printed sequence is the genome substring, and the fragment
+    name keeps the space behind '>' (countReads.cpp:46-75)."""
+    g = synth.random_genome(1_000_000, seed=1)
+    g = synth.Genome(sym=g.sym, frag_start=g.frag_start, frag_names=[" random_1000000"])
+    fa = str(tmp_path / "g.fa")
+    synth.genome_to_fasta(g, fa)
+    assert open(fa).readline() == "> random_1000000\n"
+    sub = g.sym[207:243]
+    rd = str(tmp_path / "r.fa")
+    open(rd, "w").write(">p207_inv\n%s\n" % "".join("ACGT"[c] for c in synth.revcomp(sub)))
+    out = str(tmp_path / "o.tsv")
+    r = subprocess.run([REAL, "-t", fa, "-p", rd, "-o", out, "-e", "0", "-s", "0", "-l", "32", "-q", "0"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert open(out).read() == "p207_inv\t%s\t\t1\ta\t36\t-\t random_1000000\t208\t\t0\n" % "".join("ACGT"[c] for c in sub)
+    assert "timing: " in r.stderr.decode()

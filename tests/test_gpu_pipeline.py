@@ -1,0 +1,125 @@
+"""Host-side forms of a batch on the GPU: 2-bit packed bases, the two-slot submit / wait pipeline over pinned memory,
+the version-1 batch struct, and the loud error for an under-declared read length (all through the C ABI)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from real_amd import lib as rlib
+from real_amd import synth
+from real_amd.matcher import RealOptions, UniqueMatcher, new_unique_info
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(n_reads=6000, ragged=True, seed=5):
+    g = synth.random_genome(150_000, seed=seed, n_frag=3, n_runs=6, repeats=20)
+    if ragged:
+        parts = [synth.sample_reads(g, n_reads // 3, pl, 0.02, seed=seed + pl, n_read_prob=0.0005) for pl in (36, 77, 100)]
+        bases = np.concatenate([p.bases for p in parts])
+        qual = np.concatenate([p.qual for p in parts])
+        lens = np.concatenate([np.diff(p.offsets.astype(np.int64)) for p in parts])
+        offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    else:
+        b = synth.sample_reads(g, n_reads, 100, 0.02, seed=seed + 1, n_read_prob=0.0005)
+        bases, qual, offsets = b.bases, b.qual, b.offsets
+    return g, bases, qual, offsets
+
+
+def _matcher(g, scores=True):
+    m = UniqueMatcher(RealOptions(seedl=32, seedkmax=2, totalkmax=3, scores=scores).normalise())
+    m.set_text_symbols(0, g.sym, g.frag_start)
+    m.build_index_block()
+    return m
+
+
+@pytest.mark.parametrize("ragged", [True, False])
+def test_packed_batch_equals_byte_batch(ragged):
+    g, bases, qual, offsets = _case(ragged=ragged)
+    assert (bases > 3).any()                                   # reads with N: flagged, skipped like the reference skips them
+    m = _matcher(g)
+    info, score = m.match_unique(bases, qual, offsets)
+    pk, nf = synth.pack_bases(bases), synth.read_nflags(bases, offsets)
+    if ragged:
+        pinfo, pscore = m.match_unique(pk, qual, offsets, packed=True, nflags=nf)
+    else:
+        pinfo, pscore = m.match_unique(pk, qual, None, patl=100, n_reads=offsets.shape[0] - 1, packed=True, nflags=nf)
+    assert np.array_equal(info, pinfo) and np.array_equal(score.view(np.uint32), pscore.view(np.uint32))
+    assert ((info >> np.uint64(61)) != 0).mean() > 0.5
+    # the same packed bytes handed over as device memory
+    import torch
+    dpk, dq, doff = torch.from_numpy(pk).cuda(), torch.from_numpy(qual).cuda(), torch.from_numpy(offsets.astype(np.int64)).cuda()
+    dnf = torch.from_numpy(nf).cuda()
+    di = torch.zeros(info.shape[0], dtype=torch.int64, device="cuda")
+    ds = torch.full((info.shape[0],), float(np.finfo(np.float32).min), dtype=torch.float32, device="cuda")
+    m.match_unique(dpk, dq, doff if ragged else None, patl=0 if ragged else 100, info=di, score=ds, n_reads=info.shape[0], packed=True, nflags=dnf)
+    assert np.array_equal(di.cpu().numpy().view(np.uint64), info) and np.array_equal(ds.cpu().numpy().view(np.uint32), score.view(np.uint32))
+    m.close()
+
+
+@pytest.mark.parametrize("packed,fresh", [(True, True), (False, False), (True, False)])
+def test_submit_wait_pipeline_equals_synchronous_call(packed, fresh):
+    g, bases, qual, offsets = _case(n_reads=9000, ragged=False)
+    n, patl = offsets.shape[0] - 1, 100
+    m = _matcher(g)
+    info, score = m.match_unique(bases, qual, offsets)
+    # pinned host arrays, five chunks through two slots
+    src = synth.pack_bases(bases) if packed else bases
+    hb = m.host_alloc(src.shape, np.uint8); hb[:] = src
+    hq = m.host_alloc(qual.shape, np.uint8); hq[:] = qual
+    hi = m.host_alloc((n,), np.uint64)
+    hs = m.host_alloc((n,), np.float32)
+    i0, s0 = new_unique_info(n, True)
+    hi[:] = i0 if fresh else 123                                # (fresh: whatever is in the arrays is not uploaded)
+    hs[:] = s0 if fresh else 7.0
+    if not fresh:
+        hi[:] = i0; hs[:] = s0
+    nf = synth.read_nflags(bases, offsets) if packed else None
+    chunk = 2000                                                # a multiple of 8 reads (nflags bytes) and of 4 bases (packed bytes)
+    cuts = list(range(0, n, chunk))
+    for k, lo in enumerate(cuts):
+        hi_ = min(n, lo + chunk)
+        slot = k % 2
+        m.wait(slot)
+        bpr = patl // 4 if packed else patl
+        m.submit_unique(slot, hb[lo * bpr:hi_ * bpr], hq[lo * patl:hi_ * patl], hi[lo:hi_], hs[lo:hi_], patl=patl, n_reads=hi_ - lo,
+                        packed=packed, nflags=None if nf is None else nf[lo // 8:(hi_ + 7) // 8], fresh=fresh)
+    with pytest.raises(rlib.RealHipError):                      # a slot in flight refuses another batch
+        m.submit_unique((len(cuts) - 1) % 2, hb[:100 * (patl // 4 if packed else patl)], hq[:100 * patl], hi[:100], hs[:100], patl=patl, n_reads=100, packed=packed)
+    m.wait(0); m.wait(1)
+    assert np.array_equal(np.asarray(hi), info) and np.array_equal(np.asarray(hs).view(np.uint32), score.view(np.uint32))
+    m.close()
+
+
+def test_version_1_batch_struct_is_still_accepted():
+    class BatchV1(C.Structure):
+        _fields_ = rlib.RealHipBatch._fields_[:8]
+    assert C.sizeof(BatchV1) == 48
+    g, bases, qual, offsets = _case(n_reads=900, ragged=False)
+    m = _matcher(g)
+    info, score = m.match_unique(bases, qual, offsets)
+    b = BatchV1()
+    b.struct_size, b.on_device, b.n_reads = 48, 0, offsets.shape[0] - 1
+    b.bases, b.qual, b.offsets, b.patl, b.max_patl = bases.ctypes.data, qual.ctypes.data, offsets.ctypes.data, 0, 0
+    i1, s1 = new_unique_info(int(b.n_reads), True)
+    rc = m._L.real_hip_match_unique(m._h, C.cast(C.byref(b), C.POINTER(rlib.RealHipBatch)), i1.ctypes.data, s1.ctypes.data)
+    assert rc == 0 and np.array_equal(i1, info) and np.array_equal(s1.view(np.uint32), score.view(np.uint32))
+    m.close()
+
+
+def test_under_declared_read_length_is_a_loud_error():
+    """device offsets with a caller-supplied max_patl: nothing is staged past the wave's LDS region, the call fails"""
+    import torch
+    g, bases, qual, offsets = _case(n_reads=3000, ragged=True)
+    m = _matcher(g)
+    db, dq, doff = torch.from_numpy(bases).cuda(), torch.from_numpy(qual).cuda(), torch.from_numpy(offsets.astype(np.int64)).cuda()
+    n = offsets.shape[0] - 1
+    di = torch.zeros(n, dtype=torch.int64, device="cuda")
+    ds = torch.full((n,), float(np.finfo(np.float32).min), dtype=torch.float32, device="cuda")
+    with pytest.raises(rlib.RealHipError) as e:
+        m.match_unique(db, dq, doff, info=di, score=ds, max_patl=64)            # the batch holds 77 and 100 bp reads
+    assert e.value.status == rlib.REAL_HIP_E_INVALID
+    info, score = m.match_unique(db, dq, doff, info=torch.zeros_like(di), score=ds.clone(), max_patl=100)   # the true bound: fine
+    ref_i, ref_s = m.match_unique(bases, qual, offsets)
+    assert np.array_equal(info.cpu().numpy().view(np.uint64), ref_i)
+    m.close()
