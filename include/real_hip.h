@@ -221,6 +221,32 @@ typedef struct real_hip_hit {       /* MatchPosAndError, matchAllImplementation.
 int real_hip_match_all(real_hip_ctx *ctx, const real_hip_batch *b,
                        real_hip_hit *out, uint64_t cap, uint64_t *n_out, uint64_t *hit_offsets);
 
+/* ---- multi-GPU: one process per GPU, reads sharded contiguously over the ranks, the index replicated.
+ * The path has ONE collective: the shards' results to the root, over RCCL (xGMI point-to-point links) -- a
+ * concatenation in rank order, nothing is reduced because no read is seen by two ranks.  The reference is a single
+ * process; what this replaces is the hand-over of results from its OpenMP threads to the output loop
+ * (uniqueinfo[] shared by the threads, matchUniqueImplementation.cpp:1268-1295; the per-block hit emission of
+ * matchAllImplementation.cpp:451-535).  Bootstrap: rank 0 calls real_hip_comm_id and hands the 128 bytes to the other
+ * ranks by the launcher's own means (MPI_Bcast, a file, the rendezvous store); every rank then calls
+ * real_hip_comm_init on its ctx.  All array arguments are DEVICE pointers of the ctx's device; the receive arrays
+ * matter on the root only.  Counts travel first (every rank learns every rank's sizes and the root's capacities, so a
+ * too small receive array is REAL_HIP_E_OVERFLOW on ALL ranks, with the needed sizes in *n_..._all), then the payload.
+ * A single process that drives several GPUs through several ctx (real -gpus N) needs none of this: its calls write
+ * the shards' results into the caller's host arrays directly.                                                       */
+#define REAL_HIP_COMM_ID_BYTES 128
+int real_hip_comm_id(uint8_t id[REAL_HIP_COMM_ID_BYTES]);
+int real_hip_comm_init(real_hip_ctx *ctx, const uint8_t id[REAL_HIP_COMM_ID_BYTES], int rank, int n_ranks);
+int real_hip_comm_destroy(real_hip_ctx *ctx);
+/* matchUnique: info_all / score_all (root) = the shards' records in rank order; score may be NULL iff !scores      */
+int real_hip_gather_records(real_hip_ctx *ctx, int root, const uint64_t *info, const float *score, uint64_t n_local,
+                            uint64_t *info_all, float *score_all, uint64_t cap_all, uint64_t *n_all);
+/* matchAll: the shards' unified hit lists as real_hip_match_all returned them (hit_offsets: n_local + 1 entries);
+ * on the root hits_all holds all hits with .read rebased to the whole batch and offsets_all (n_reads_all + 1) the
+ * rebased offsets                                                                                                   */
+int real_hip_gather_hits(real_hip_ctx *ctx, int root, const real_hip_hit *hits, const uint64_t *hit_offsets, uint64_t n_local,
+                         uint64_t n_hits_local, real_hip_hit *hits_all, uint64_t cap_hits, uint64_t *offsets_all, uint64_t cap_reads,
+                         uint64_t *n_reads_all, uint64_t *n_hits_all);
+
 /* ---- read ingestion on the device: FASTA / FASTQ text -> the arrays of a batch.
  * Replaces FastQReader / FastAReader::getNextPatternUnlocked (FastQReader.hpp:130-180,
  * FastAReader.hpp:107-138), Pattern::computeMapped (Pattern.hpp:105-128, acgtnMap.hpp:39-50) and the

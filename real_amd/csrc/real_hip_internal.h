@@ -161,6 +161,11 @@ struct real_hip_ctx {
     double   alloc_ms = 0, free_ms = 0, build_wall_ms = 0;
     uint64_t alloc_bytes = 0, alloc_calls = 0, free_calls = 0;
 
+    // multi-GPU (gather.hip): an RCCL communicator over the ranks' devices, one process per GPU
+    void *comm = nullptr;
+    int comm_rank = 0, comm_size = 1;
+    DevBuf comm_counts, comm_scratch;
+
     // timing
     bool timing = true;
     double   k_ms[REAL_HIP_K_COUNT] = {};
@@ -200,6 +205,7 @@ struct RhTimer { // HIP events on the ctx stream around a group of launches
 };
 
 // ---- kernels launchers (match_kernels.hip) -----------------------------------
+void rh_comm_destroy(real_hip_ctx *ctx);
 int rh_launch_match(real_hip_ctx *ctx, const MatchArgs &a, bool all, int state_slot);
 int rh_match_finish(real_hip_ctx *ctx, int state_slot); // after the launch has completed: errors the kernels flagged
 int rh_unpack_bases(real_hip_ctx *ctx, const uint8_t *d_packed, uint64_t n_symbols, const uint8_t *d_nflags, const uint64_t *d_off,

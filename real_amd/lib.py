@@ -33,6 +33,7 @@ ABI_SYMBOLS = [
     "real_hip_set_index_block", "real_hip_build_index_block", "real_hip_index_info", "real_hip_index_build_stats",
     "real_hip_index_table_kind", "real_hip_index_download", "real_hip_index_export", "real_hip_match_unique", "real_hip_match_all", "real_hip_match_unique_submit", "real_hip_wait",
     "real_hip_host_alloc", "real_hip_host_free",
+    "real_hip_comm_id", "real_hip_comm_init", "real_hip_comm_destroy", "real_hip_gather_records", "real_hip_gather_hits",
     "real_hip_parse_reads", "real_hip_download", "real_hip_counters_get", "real_hip_kernel_time", "real_hip_timing_enable",
 ]
 
@@ -126,6 +127,11 @@ def load():
     L.real_hip_host_alloc.restype = vp
     L.real_hip_host_free.argtypes = [vp]
     L.real_hip_host_free.restype = None
+    L.real_hip_comm_id.argtypes = [vp]
+    L.real_hip_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.real_hip_comm_destroy.argtypes = [vp]
+    L.real_hip_gather_records.argtypes = [vp, C.c_int, vp, vp, u64, vp, vp, u64, C.POINTER(u64)]
+    L.real_hip_gather_hits.argtypes = [vp, C.c_int, vp, vp, u64, u64, vp, u64, vp, u64, C.POINTER(u64), C.POINTER(u64)]
     L.real_hip_match_all.argtypes = [vp, C.POINTER(RealHipBatch), vp, u64, C.POINTER(u64), vp]
     L.real_hip_counters_get.argtypes = [vp, C.POINTER(RealHipCounters), C.c_int]
     L.real_hip_kernel_time.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(u64), C.c_int]

@@ -333,6 +333,38 @@ class HipMatcher:
     def wait(self, slot: int):
         self._check(self._L.real_hip_wait(self._h, slot))
 
+    # -- multi-GPU: the C ABI's own RCCL gather (one process per GPU; torch.distributed is the other way, real_amd.distributed) --
+    @staticmethod
+    def comm_id() -> bytes:
+        """rank 0: the 128 bytes every rank hands to comm_init (broadcast them by the launcher's own means)"""
+        buf = (C.c_uint8 * 128)()
+        rc = _lib.load().real_hip_comm_id(buf)
+        if rc != 0:
+            raise RealHipError(rc, "real_hip_comm_id (librccl could not be loaded?)")
+        return bytes(buf)
+
+    def comm_init(self, comm_id: bytes, rank: int, n_ranks: int):
+        buf = (C.c_uint8 * 128).from_buffer_copy(comm_id)
+        self._check(self._L.real_hip_comm_init(self._h, buf, rank, n_ranks))
+
+    def gather_records(self, root: int, info, score, info_all=None, score_all=None) -> int:
+        """device tensors; returns the number of records on the root (real_hip_gather_records)"""
+        self.sync_inputs(info, score, info_all, score_all)
+        n_all = C.c_uint64(0)
+        cap = int(info_all.shape[0]) if info_all is not None else 0
+        self._check(self._L.real_hip_gather_records(self._h, root, _ptr(info), _ptr(score), int(info.shape[0]), _ptr(info_all), _ptr(score_all), cap, C.byref(n_all)))
+        return int(n_all.value)
+
+    def gather_hits(self, root: int, hits, hit_offsets, n_hits: int, hits_all=None, offsets_all=None):
+        """device tensors: hits [n, 4] int32 (real_hip_hit records), hit_offsets [n_local + 1] int64; returns (reads, hits) on the root"""
+        self.sync_inputs(hits, hit_offsets, hits_all, offsets_all)
+        nr, nh = C.c_uint64(0), C.c_uint64(0)
+        cap_h = int(hits_all.shape[0]) if hits_all is not None else 0
+        cap_r = int(offsets_all.shape[0]) - 1 if offsets_all is not None else 0
+        self._check(self._L.real_hip_gather_hits(self._h, root, _ptr(hits), _ptr(hit_offsets), int(hit_offsets.shape[0]) - 1, int(n_hits), _ptr(hits_all), cap_h,
+                                                 _ptr(offsets_all), cap_r, C.byref(nr), C.byref(nh)))
+        return int(nr.value), int(nh.value)
+
     # -- read ingestion on the device --
     def parse_reads(self, text, fastq: bool, quality_offset: int = 33):
         """FASTA / FASTQ text (bytes, numpy uint8 or a device torch tensor) -> RealHipParsed: device arrays owned by the

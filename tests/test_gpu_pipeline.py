@@ -123,3 +123,42 @@ def test_under_declared_read_length_is_a_loud_error():
     ref_i, ref_s = m.match_unique(bases, qual, offsets)
     assert np.array_equal(info.cpu().numpy().view(np.uint64), ref_i)
     m.close()
+
+
+def test_c_abi_rccl_gather_single_rank():
+    """real_hip_comm_* / real_hip_gather_*: the C-side form of the path's one collective (RCCL, one process per GPU),
+    exercised here with a communicator of one rank -- counts exchange, grouped send/recv to self, rebasing kernels.
+    (More ranks need more GPUs than this box has; the N-rank bench path runs over torch.distributed.)"""
+    import torch
+    from real_amd.matcher import AllMatcher, HipMatcher
+    g, bases, qual, offsets = _case(n_reads=3000, ragged=False)
+    n = offsets.shape[0] - 1
+    m = _matcher(g)
+    db, dq = torch.from_numpy(bases).cuda(), torch.from_numpy(qual).cuda()
+    di = torch.zeros(n, dtype=torch.int64, device="cuda")
+    ds = torch.full((n,), float(np.finfo(np.float32).min), dtype=torch.float32, device="cuda")
+    m.match_unique(db, dq, patl=100, info=di, score=ds, n_reads=n)
+    m.comm_init(HipMatcher.comm_id(), 0, 1)
+    ai, as_ = torch.zeros(n + 5, dtype=torch.int64, device="cuda"), torch.zeros(n + 5, dtype=torch.float32, device="cuda")
+    assert m.gather_records(0, di, ds, ai, as_) == n
+    assert torch.equal(ai[:n], di) and torch.equal(as_[:n].view(torch.int32), ds.view(torch.int32))
+    with pytest.raises(rlib.RealHipError) as e:                                 # a receive array that is too small: loud, on every rank
+        m.gather_records(0, di, ds, ai[:10], as_[:10])
+    assert e.value.status == rlib.REAL_HIP_E_OVERFLOW
+    # matchAll hit lists
+    m.set_match_params(totalkmax=2)
+    import ctypes as C
+    cap = 8 * n
+    hits = torch.zeros((cap, 4), dtype=torch.int32, device="cuda")
+    hoff = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+    b = m._batch(db, dq, None, 100, n)
+    nout = C.c_uint64(0)
+    m.sync_inputs(db)
+    m._check(m._L.real_hip_match_all(m._h, C.byref(b), hits.data_ptr(), cap, C.byref(nout), hoff.data_ptr()))
+    nh = int(nout.value)
+    assert nh > n // 2
+    ah = torch.zeros((nh + 7, 4), dtype=torch.int32, device="cuda")
+    ao = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+    assert m.gather_hits(0, hits, hoff, nh, ah, ao) == (n, nh)
+    assert torch.equal(ah[:nh], hits[:nh]) and torch.equal(ao, hoff)
+    m.close()
