@@ -119,38 +119,69 @@ struct Ranges { std::vector<std::vector<std::string>> names; std::vector<std::ve
 
 // ---- output lines (printMatchUnlocked, matchUniqueImplementation.cpp:252-321) --------------------------
 // id \t sequence as matched \t score|"" \t 1 \t a \t patl \t +|- \t fragment name \t 1-based position \t "" \t errors \n
-inline void appendTail(std::string &out, bool scores, float score, uint64_t patl, bool inverted, const std::string &fragname, uint64_t pos1,
-                       unsigned errors)
+// Written straight into the thread's buffer: table lookups for the sequence, hand-rolled decimal numbers; only the score
+// goes through printf's %g (operator<<(float) is %g with six significant digits: the same digits by the same code).
+struct SeqTables {
+    char fwd[256], rc[256], map_fwd[5], map_rc[5];
+    SeqTables()
+    {
+        for (int c = 0; c < 256; ++c) { fwd[c] = 'N'; rc[c] = 'N'; }   // anything but ACGT (lowercase too) maps to 4 and prints as N
+        fwd['A'] = 'A'; fwd['C'] = 'C'; fwd['G'] = 'G'; fwd['T'] = 'T';
+        rc['A'] = 'T'; rc['C'] = 'G'; rc['G'] = 'C'; rc['T'] = 'A';
+        memcpy(map_fwd, "ACGTN", 5); memcpy(map_rc, "TGCAN", 5);       // remapChar, acgtnMap.hpp:24-35; transposed: 3 - c
+    }
+};
+const SeqTables kSeq;
+
+inline char *putUint(char *p, uint64_t v)
 {
-    char buf[96];
-    out.push_back('\t');
-    if (scores) out.append(buf, (size_t)snprintf(buf, sizeof buf, "%g", (double)score)); // operator<<(float): %g, six digits
-    out.append(buf, (size_t)snprintf(buf, sizeof buf, "\t1\ta\t%llu\t%c\t", (unsigned long long)patl, inverted ? '-' : '+'));
-    out.append(fragname);
-    out.append(buf, (size_t)snprintf(buf, sizeof buf, "\t%llu\t\t%u\n", (unsigned long long)pos1, errors));
+    char tmp[24];
+    int n = 0;
+    do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) *p++ = tmp[--n];
+    return p;
 }
-// the sequence column from mapped symbols: remapChar (acgtnMap.hpp:24-35) of the pattern, or of its transposed form
-inline void appendSeqMapped(std::string &out, const uint8_t *m, uint64_t n, bool inverted)
+// room for one line behind the current end of out; returns the write position
+inline char *lineRoom(std::string &out, size_t bytes)
 {
     const size_t at = out.size();
-    out.resize(at + n);
-    char *d = &out[at];
-    if (!inverted) for (uint64_t i = 0; i < n; ++i) d[i] = m[i] < 4 ? "ACGT"[m[i]] : 'N';
-    else for (uint64_t i = 0; i < n; ++i) { const uint8_t c = m[n - 1 - i]; d[i] = c < 4 ? "TGCA"[c] : 'N'; }
+    if (out.capacity() < at + bytes) out.reserve(std::max(out.capacity() * 2, at + bytes));
+    out.resize(at + bytes);
+    return &out[at];
 }
-// ... or straight from the characters of the read file (same mapping: anything but ACGT, lowercase too, prints as N)
-inline void appendSeqText(std::string &out, const char *t, uint64_t n, bool inverted)
+inline char *putTail(char *p, bool scores, float score, uint64_t patl, bool inverted, const std::string &fragname, uint64_t pos1, unsigned errors)
+{
+    *p++ = '\t';
+    if (scores) p += snprintf(p, 32, "%g", (double)score);
+    memcpy(p, "\t1\ta\t", 5); p += 5;
+    p = putUint(p, patl);
+    *p++ = '\t'; *p++ = inverted ? '-' : '+'; *p++ = '\t';
+    memcpy(p, fragname.data(), fragname.size()); p += fragname.size();
+    *p++ = '\t';
+    p = putUint(p, pos1);
+    *p++ = '\t'; *p++ = '\t';
+    p = putUint(p, errors);
+    *p++ = '\n';
+    return p;
+}
+// one line; the sequence column from the characters of the read file (seq_text) or from mapped symbols (seq_mapped)
+inline void appendLine(std::string &out, const char *id, size_t idlen, const char *seq_text, const uint8_t *seq_mapped, uint64_t patl, bool scores,
+                       float score, bool inverted, const std::string &fragname, uint64_t pos1, unsigned errors)
 {
     const size_t at = out.size();
-    out.resize(at + n);
-    char *d = &out[at];
-    if (!inverted)
-        for (uint64_t i = 0; i < n; ++i) { const char c = t[i]; d[i] = (c == 'A' || c == 'C' || c == 'G' || c == 'T') ? c : 'N'; }
-    else
-        for (uint64_t i = 0; i < n; ++i) {
-            const char c = t[n - 1 - i];
-            d[i] = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N';
-        }
+    char *p = lineRoom(out, idlen + patl + fragname.size() + 112), *p0 = p;
+    memcpy(p, id, idlen); p += idlen;
+    *p++ = '\t';
+    if (seq_text) {
+        if (!inverted) for (uint64_t i = 0; i < patl; ++i) p[i] = kSeq.fwd[(unsigned char)seq_text[i]];
+        else for (uint64_t i = 0; i < patl; ++i) p[i] = kSeq.rc[(unsigned char)seq_text[patl - 1 - i]];
+    } else {
+        if (!inverted) for (uint64_t i = 0; i < patl; ++i) p[i] = kSeq.map_fwd[seq_mapped[i] < 4 ? seq_mapped[i] : 4];
+        else for (uint64_t i = 0; i < patl; ++i) { const uint8_t c = seq_mapped[patl - 1 - i]; p[i] = kSeq.map_rc[c < 4 ? c : 4]; }
+    }
+    p += patl;
+    p = putTail(p, scores, score, patl, inverted, fragname, pos1, errors);
+    out.resize(at + (size_t)(p - p0));
 }
 
 struct Record { unsigned st, frag, errors, file; uint64_t pos; };
@@ -167,18 +198,20 @@ template <class LineFn>
 void formatAndWrite(uint64_t n, FILE *out, Timers &T, LineFn line)
 {
     const int nt = std::max(1, omp_get_max_threads());
-    std::vector<std::string> buf((size_t)nt);
+    static std::vector<std::string> buf; // (kept across calls: the pages of a buffer are touched once, not once per block)
+    if ((int)buf.size() < nt) buf.resize((size_t)nt);
     const double t0 = now_s();
 #pragma omp parallel num_threads(nt)
     {
         const int t = omp_get_thread_num();
         const uint64_t lo = n * (uint64_t)t / nt, hi = n * (uint64_t)(t + 1) / nt;
         std::string &b = buf[(size_t)t];
-        b.reserve((size_t)(hi - lo) * 64);
+        b.clear();
         for (uint64_t i = lo; i < hi; ++i) line(i, b);
     }
     const double t1 = now_s();
-    for (auto &b : buf) {
+    for (int t = 0; t < nt; ++t) {
+        const std::string &b = buf[(size_t)t];
         if (!b.empty() && fwrite(b.data(), 1, b.size(), out) != b.size()) throw std::runtime_error("write to the output file failed");
         T.out_bytes += b.size();
     }
@@ -513,10 +546,8 @@ int matchUnique(const RealOptions &o)
                     uint64_t il = id_len[i];
                     if (text[id_start[i] + il] == '\r') il++;
                     const uint64_t patl = off[i + 1] - off[i];
-                    b.append(text + id_start[i], il);
-                    b.push_back('\t');
-                    appendSeqText(b, text + id_start[i] + il + 1, patl, r.st == 2);
-                    appendTail(b, o.scores, o.scores ? score[base + i] : 0.f, patl, r.st == 2, RS.names[r.file][r.frag], r.pos - RS.starts[r.file][r.frag] + 1, r.errors);
+                    appendLine(b, text + id_start[i], il, text + id_start[i] + il + 1, nullptr, patl, o.scores, o.scores ? score[base + i] : 0.f, r.st == 2,
+                               RS.names[r.file][r.frag], r.pos - RS.starts[r.file][r.frag] + 1, r.errors);
                     cnt[(size_t)omp_get_thread_num()]++;
                 });
                 for (uint64_t c : cnt) unique += c;
@@ -530,10 +561,8 @@ int matchUnique(const RealOptions &o)
                     const Record r = unpack(info[b.first_id + i]);
                     if (r.st != 1 && r.st != 2) return;
                     const uint64_t lo = b.offsets[i], patl = b.offsets[i + 1] - lo;
-                    s.append(b.ids[i]);
-                    s.push_back('\t');
-                    appendSeqMapped(s, &b.bases[lo], patl, r.st == 2);
-                    appendTail(s, o.scores, o.scores ? score[b.first_id + i] : 0.f, patl, r.st == 2, RS.names[r.file][r.frag], r.pos - RS.starts[r.file][r.frag] + 1, r.errors);
+                    appendLine(s, b.ids[i].data(), b.ids[i].size(), nullptr, &b.bases[lo], patl, o.scores, o.scores ? score[b.first_id + i] : 0.f, r.st == 2,
+                               RS.names[r.file][r.frag], r.pos - RS.starts[r.file][r.frag] + 1, r.errors);
                     cnt[(size_t)omp_get_thread_num()]++;
                 });
                 for (uint64_t c : cnt) unique += c;
@@ -616,10 +645,8 @@ int matchAll(const RealOptions &o)
                         const uint64_t lo = b.offsets[i], patl = b.offsets[i + 1] - lo;
                         for (uint64_t k = hoff[g][i]; k < hoff[g][i + 1]; ++k) {
                             const real_hip_hit &M = hits[g][k];
-                            s.append(b.ids[i]);
-                            s.push_back('\t');
-                            appendSeqMapped(s, &b.bases[lo], patl, M.inverted);
-                            appendTail(s, o.scores, M.score, patl, M.inverted, R.G.frag_names[M.frag], (uint64_t)M.pos - R.G.frag_start[M.frag] + 1, M.k);
+                            appendLine(s, b.ids[i].data(), b.ids[i].size(), nullptr, &b.bases[lo], patl, o.scores, M.score, M.inverted != 0,
+                                       R.G.frag_names[M.frag], (uint64_t)M.pos - R.G.frag_start[M.frag] + 1, M.k);
                         }
                     });
                 }
