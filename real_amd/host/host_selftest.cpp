@@ -33,6 +33,8 @@ int main(int argc, char **argv)
             dump(d + "/frag.u64", G.frag_start.data(), G.frag_start.size());
             std::ofstream n((d + "/names.txt").c_str());
             for (auto &s : G.frag_names) n << s << "\n";
+            std::ofstream nb((d + "/names.bin").c_str(), std::ios::binary); // (names may hold any byte but NUL)
+            for (auto &s : G.frag_names) { nb.write(s.data(), (std::streamsize)s.size()); nb.put('\0'); }
             std::vector<uint64_t> t, w; G.pack(t, w);
             dump(d + "/text.u64", t.data(), t.size()); dump(d + "/wild.u64", w.data(), w.size());
             return 0;
@@ -44,12 +46,14 @@ int main(int argc, char **argv)
             ReadReader rr(argv[2], fq, qoff ? qoff : det);
             ReadBlock all, b; all.clear();
             std::ofstream ids((d + "/ids.txt").c_str());
+            std::ofstream idb((d + "/ids.bin").c_str(), std::ios::binary);
             while (rr.fillBlock(b, 7, true)) { // tiny blocks: exercises the block boundaries
                 for (uint64_t i = 0; i < b.size(); ++i) {
                     all.bases.insert(all.bases.end(), b.bases.begin() + b.offsets[i], b.bases.begin() + b.offsets[i + 1]);
                     all.qual.insert(all.qual.end(), b.qual.begin() + b.offsets[i], b.qual.begin() + b.offsets[i + 1]);
                     all.offsets.push_back(all.bases.size());
                     ids << b.ids[i] << "\n";
+                    idb.write(b.ids[i].data(), (std::streamsize)b.ids[i].size()); idb.put('\0');
                 }
             }
             dump(d + "/bases.u8", all.bases.data(), all.bases.size()); dump(d + "/qual.u8", all.qual.data(), all.qual.size());

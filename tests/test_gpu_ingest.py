@@ -149,3 +149,46 @@ def test_match_from_parsed_text_equals_match_from_arrays(ora):
     info1, score1 = m.match_unique_parsed(p)
     assert np.array_equal(info0, info1) and np.array_equal(score0.view(np.uint32), score1.view(np.uint32))
     m.close()
+
+
+def _golden_reader_cases():
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "readers.npz"))
+    return z, sorted({k.split("/")[0] for k in z.files if not k.startswith("g_")})
+
+
+@pytest.mark.parametrize("case", _golden_reader_cases()[1])
+def test_device_parser_equals_the_reference_readers_or_refuses(case):
+    """tests/golden/readers.npz: what the REFERENCE's FastQReader / FastAReader (compiled, oracle/ref_readers.cpp) make of
+    tricky texts.  Text in one-line-per-field form must come out of real_hip_parse_reads exactly like that -- mapped
+    symbols, qualities minus the detected offset, lengths, ids (a '\\r' in front of the newline belongs to the id) --
+    and everything else must be refused with REAL_HIP_E_UNSUPPORTED (the host reader, pinned by the same fixture in
+    tests/test_reader_golden.py, takes it)."""
+    from real_amd import lib as rlib
+    z, _ = _golden_reader_cases()
+    text = z[case + "/input"].tobytes()
+    cnt, det, n = [int(x) for x in z[case + "/meta"]]
+    fastq = case.startswith("fq_")
+    canonical = case in ("fq_canonical_q33", "fq_q64", "fq_crlf", "fq_lowercase_iupac_n", "fq_at_in_quality", "fq_no_final_newline",
+                         "fq_ragged_lengths", "fa_canonical", "fa_crlf", "fa_no_final_newline")
+    m = UniqueMatcher(_opts().normalise())
+    if not canonical:
+        with pytest.raises(RealHipError) as e:
+            m.parse_reads(text, fastq=fastq, quality_offset=det or 33)
+        assert e.value.status == rlib.REAL_HIP_E_UNSUPPORTED
+        m.close()
+        return
+    p = m.parse_reads(text, fastq=fastq, quality_offset=det)
+    assert p.n_reads == n == cnt
+    assert np.array_equal(m.download(p.offsets, n + 1, np.uint64), z[case + "/off"])
+    assert np.array_equal(m.download(p.bases, int(p.n_symbols), np.uint8), z[case + "/bases"])
+    if fastq:
+        assert np.array_equal(m.download(p.qual, int(p.n_symbols), np.uint8), z[case + "/qual"])
+    ids0, idl = m.download(p.id_start, n, np.uint32), m.download(p.id_len, n, np.uint32)
+    got = b""
+    for s, l in zip(ids0.tolist(), idl.tolist()):
+        if text[s + l:s + l + 1] == b"\r":               # (the rule of the output formatter, real_amd/host/real.cpp)
+            l += 1
+        got += text[s:s + l] + b"\0"
+    assert got == z[case + "/ids"].tobytes()
+    m.close()

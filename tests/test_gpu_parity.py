@@ -14,7 +14,7 @@ from real_amd.matcher import AllMatcher, RealOptions, UniqueMatcher, new_unique_
 
 pytestmark = pytest.mark.gpu
 
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+GOLDEN = sorted(f for f in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")) if os.path.basename(f) != "readers.npz")   # (readers.npz: tests/test_reader_golden.py)
 
 
 def _opts(seedl, seedkmax, totalkmax, scores, filter_level=2):
