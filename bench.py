@@ -148,6 +148,14 @@ def gen_reads(torch, sym, n_reads, patl, errprob, seed, device, shuffle=False):
     return bases, qual, pos, inv
 
 
+def pack_bases(torch, bases, n_reads, patl):
+    """one symbol per byte -> 2 bits per base, four per byte, MSB first (real_hip_batch.packed; the reads of the workload
+    hold no N).  What the matcher reads from HBM per 100 bp read drops from 100 to 25 bytes of bases."""
+    assert patl % 4 == 0
+    q4 = bases.view(n_reads * (patl // 4), 4)
+    return ((q4[:, 0] << 6) | (q4[:, 1] << 4) | (q4[:, 2] << 2) | q4[:, 3]).to(torch.uint8)
+
+
 def strided_sample(torch, bases, qual, n_reads, patl, k):
     """k reads of the batch at a constant stride, as host arrays (no gather kernels on >2^31-element tensors)"""
     stride = max(1, n_reads // max(k, 1))
@@ -199,7 +207,7 @@ class CpuSide:
 # ---------------------------------------------------------------------------------------------
 # timed loops
 # ---------------------------------------------------------------------------------------------
-def timed_unique(torch, dist, m, rlib, bases, qual, patl, n, steps, warmup, world, rank, dev, gather_dev, log=None):
+def timed_unique(torch, dist, m, rlib, bases, qual, patl, n, steps, warmup, world, rank, dev, gather_dev, log=None, packed=False):
     """K steps of matchUnique over the resident batch, bracketed by barrier + synchronize on both sides, MAX over
     ranks.  N > 1: the records of step k travel to the root while step k+1 is matched (two alternating record
     buffers).  Returns (seconds, counters, (match_ms, launches), (repeat_ms, launches), last (info, score))."""
@@ -222,7 +230,7 @@ def timed_unique(torch, dist, m, rlib, bases, qual, patl, n, steps, warmup, worl
         if rg is not None:
             rg.wait(slot)                                       # the gather that last read this buffer
         bi.zero_(); bs.fill_(NO_SCORE)                          # uniqueinfo(numpat): state NoMatch, score -FLT_MAX
-        m.match_unique(bases, qual, patl=patl, info=bi, score=bs, n_reads=n)
+        m.match_unique(bases, qual, patl=patl, info=bi, score=bs, n_reads=n, packed=packed)
         if rg is not None:                                      # the one collective: records to the root
             if gather_dev == "cpu":
                 rg.start(slot, bi.cpu(), bs.cpu())
@@ -363,6 +371,9 @@ def main():
                     help="C3 / C5 / shuffled reads / host-inclusive side measurements in the line's \"extra\" (auto: at N=1 on the BASELINE workload)")
     ap.add_argument("--extra-steps", type=int, default=5)
     ap.add_argument("--shuffle-reads", action="store_true", help="reads in random order instead of genpat's sorted order")
+    ap.add_argument("--input-format", choices=["packed", "bytes"], default="packed",
+                    help="the resident batch the timed region starts from: 2-bit packed bases (SURVEY 8d: pre-packed read batches; what B_io of the "
+                         "algorithmic-bytes formula counts) or one mapped symbol per byte (the decoded pattern block of the reference); qualities are a byte per base in both")
     ap.add_argument("--host-buffers", action="store_true",
                     help="hand the batch over as host buffers (PCIe-inclusive rate; never the headline value)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -478,8 +489,10 @@ def main():
         return
 
     # ---- the headline: C2 (or C4 = N x C2)
+    packed = args.input_format == "packed" and args.patl % 4 == 0
+    pk = pack_bases(torch, bases, n, args.patl) if packed else None
     dt, ctr, (match_ms, match_n), (rep_ms, rep_n), (info, score) = timed_unique(
-        torch, dist, m, rlib, bases, qual, args.patl, n, args.steps, args.warmup, world, rank, dev, gather_dev, log)
+        torch, dist, m, rlib, pk if packed else bases, qual, args.patl, n, args.steps, args.warmup, world, rank, dev, gather_dev, log, packed=packed)
     log("timed steps done: %.1f ms/step" % (dt / args.steps * 1e3))
 
     if rank == 0:
@@ -504,6 +517,8 @@ def main():
                        "genome_bp": G, "reads_per_gpu_per_step": n, "read_len": args.patl, "seedl": args.seedl,
                        "seedkmax": 2, "totalkmax": args.totalk, "scores": bool(args.scores), "errprob": 0.02,
                        "read_order": "shuffled" if args.shuffle_reads else "sorted by position (genpat.cpp:99)",
+                       "input_format": ("2-bit packed bases (25 B per 100 bp read) + one quality byte per base, resident in HBM" if packed
+                                        else "one mapped symbol per byte + one quality byte per base, resident in HBM"),
                        "index_entries": n_entries, "prefix_bits": m.prefix_bits, "bucket_tables": TABLE_KINDS[m.table_kind],
                        "parallelism": "reads sharded x%d, index replicated, one RCCL gather of records" % world,
                        "distributed": dist_info,
@@ -526,8 +541,8 @@ def main():
             out["cpu_baseline"] = None
         if extras_on:
             del info, score
-            reads = [bases, qual, true_pos, true_inv]
-            del bases, qual, true_pos, true_inv                 # (C5 needs the room: extras() frees them before its index build)
+            reads = [bases, qual, true_pos, true_inv, pk]
+            del bases, qual, true_pos, true_inv, pk             # (C5 needs the room: extras() frees them before its index build)
             out["extra"] = extras(torch, dist, rlib, args, m, opts, cpu, sym, sym_host, frag, reads, n, G, dev, log)
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -539,10 +554,24 @@ def main():
 # side measurements carried in the line's "extra" (N = 1)
 # ---------------------------------------------------------------------------------------------
 def extras(torch, dist, rlib, args, m, opts, cpu, sym, sym_host, frag, reads, n, G, dev, log):
-    bases, qual = reads[0], reads[1]
+    bases, qual, pk = reads[0], reads[1], reads[4]
     ex = {}
     K = max(1, args.extra_steps)
     patl = args.patl
+
+    # (0) the same step from the other resident input format
+    try:
+        other_packed = pk is None and patl % 4 == 0
+        ob = pack_bases(torch, bases, n, patl) if other_packed else bases
+        dt, ctr, (ms, ln), (rms, rn), _ = timed_unique(torch, dist, m, rlib, ob, qual, patl, n, K, 1, 1, 0, dev, dev, packed=other_packed)
+        ex["c2_packed_bases" if other_packed else "c2_byte_bases"] = {
+            "ms_per_step": dt / K * 1e3, "reads_per_s": n * K / dt, "avg_match_kernel_ms": ms / max(ln, 1),
+            "note": ("the headline's step with the bases as 2 bits per base" if other_packed else
+                     "the headline's step with the bases as one mapped symbol per byte (the decoded pattern block of the reference; the round-1 headline format)")}
+        del ob
+        log("extra: %s bases %.1f ms/step" % ("packed" if other_packed else "byte", dt / K * 1e3))
+    except Exception as e:
+        ex["c2_other_input_format"] = {"error": repr(e)}
 
     # (1) the same step on the same reads in shuffled order (a sequencer does not sort; genpat does)
     try:
@@ -550,7 +579,10 @@ def extras(torch, dist, rlib, args, m, opts, cpu, sym, sym_host, frag, reads, n,
         sb = bases.view(n, patl)[perm].contiguous().view(-1)
         sq = qual.view(n, patl)[perm].contiguous().view(-1)
         del perm
-        dt, ctr, (ms, ln), (rms, rn), _ = timed_unique(torch, dist, m, rlib, sb, sq, patl, n, K, 1, 1, 0, dev, dev)
+        spk = pk is not None
+        if spk:
+            sb = pack_bases(torch, sb, n, patl)
+        dt, ctr, (ms, ln), (rms, rn), _ = timed_unique(torch, dist, m, rlib, sb, sq, patl, n, K, 1, 1, 0, dev, dev, packed=spk)
         ex["c2_shuffled_reads"] = {"ms_per_step": dt / K * 1e3, "reads_per_s": n * K / dt, "avg_match_kernel_ms": ms / max(ln, 1),
                                    "note": "the step's 50M reads in a random order: consecutive lanes verify unrelated text"}
         del sb, sq
@@ -672,11 +704,10 @@ def host_inclusive(torch, m, rlib, bases, qual, patl, n, log, steps=2, chunk=5_0
     hi = m.host_alloc((n,), np.uint64)
     hs = m.host_alloc((n,), np.float32)
     # pack on the device (4 bases per byte, MSB first), bring both arrays to the pinned buffers once
-    q4 = bases.view(n * bpr, 4)
-    pk = ((q4[:, 0] << 6) | (q4[:, 1] << 4) | (q4[:, 2] << 2) | q4[:, 3]).to(torch.uint8)
+    pk = pack_bases(torch, bases, n, patl)
     torch.from_numpy(hb).copy_(pk)
     torch.from_numpy(hq).copy_(qual)
-    del pk, q4
+    del pk
     torch.cuda.synchronize()
     cuts = list(range(0, n, chunk))
 

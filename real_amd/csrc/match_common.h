@@ -77,6 +77,26 @@ __device__ __forceinline__ bool pack_read(const Row &row, uint32_t patl, uint64_
     return ok;
 }
 
+// the same from 2-bit packed bases (4 per byte, MSB first = the byte order of a word of the read read big-endian);
+// patl is a multiple of 4
+template <int W, class Row>
+__device__ __forceinline__ void pack_read_packed(const Row &row, uint32_t patl, uint64_t *O)
+{
+    const uint32_t nbytes = patl >> 2;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        uint64_t w = 0;
+        if (8u * j < nbytes) {
+            const uint32_t hi = __builtin_bswap32(row.dword(8 * j, nbytes));
+            const uint32_t lo = (8u * j + 4 < nbytes) ? __builtin_bswap32(row.dword(8 * j + 4, nbytes)) : 0u;
+            w = ((uint64_t)hi << 32) | lo;
+            const uint32_t rem = nbytes - 8u * j; // bytes of this word that belong to the read
+            if (rem < 8) w &= ~0ull << (64 - 8 * rem);
+        }
+        O[j] = w;
+    }
+}
+
 // seed halves (m0|m1), (m2|m3) of read[0..l) and of its reverse complement
 // (SignatureConstruction.hpp:347-410)
 template <int W>

@@ -31,6 +31,11 @@
 // arithmetic (no MFMA: XOR/popcount and a short FP64 add chain).
 #include "match_common.h"
 
+// RH_ABLATE (experimental builds only, make variant): bit 0 no scoring, bit 1 no verification of queued candidates,
+// bit 2 no entries examined, bit 3 bucket rows fetched but not decoded -- results are wrong, the time tells what a stage costs
+#ifndef RH_ABLATE
+#define RH_ABLATE 0
+#endif
 #define EB 8  // index entries a lane requests per round trip while enumerating equal ranges
 #define MQ 16 // candidate queue slots per lane (LDS); a full queue is drained and refilled
 // LDS bytes of one wave: its candidate queue (MQ x 64 positions + lists, 6 x 64 cursors; the first 6.5 KiB) while
@@ -106,7 +111,7 @@ __device__ __forceinline__ void flush_pending(const MatchArgs &a, LaneState<W, S
     float sc[NPEND] = {1.0f, 1.0f};
 #pragma unroll 1
     for (uint32_t j = 0; j < s.p_n; ++j) {
-        if (!SCORES) break; // ComputeScore<...,false>: 1.0f (ComputeScore.hpp:31-45)
+        if (!SCORES || (RH_ABLATE & 1)) break; // ComputeScore<...,false>: 1.0f (ComputeScore.hpp:31-45)
         const uint32_t pos = j ? s.p_pos[1] : s.p_pos[0], meta = j ? s.p_meta[1] : s.p_meta[0];
         const uint32_t inv = (meta >> 8) & 1;
         uint64_t Ow[W], tw[W];
@@ -160,6 +165,7 @@ __device__ __forceinline__ void process_candidate(const MatchArgs &a, LaneState<
                                                   uint32_t rpos, uint32_t lmask)
 {
     if (s.p_n == PEND_OVF) return; // handed over
+    if (RH_ABLATE & 2) return;
     const uint64_t *__restrict__ T = a.t.text;
     const uint32_t bb = a.b_bits;
     const uint64_t mb = (bb >= 64) ? ~0ull : ((1ull << bb) - 1);
@@ -630,7 +636,7 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
         wave_lds_sync();
         if (li + 1 < NL) ISSUE_ROWS(la + 1); // the next list's rows are in flight while this one is decoded and drained
         // owners: directory of the row, then the entries of their key group
-        const bool mine = act && !(s.p_n == PEND_OVF);
+        const bool mine = act && !(s.p_n == PEND_OVF) && !(RH_ABLATE & 8);
         const uint8_t *rowb = rowbuf + lane * 128;
         const uint32_t sw = lane & 7;
         auto row = [&](uint32_t d) { return *reinterpret_cast<const uint32_t *>(rowb + ((((d >> 2) ^ sw) << 4) | ((d & 3) << 2))); };
@@ -687,6 +693,7 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
             if (!wide) s.cC += e_cnt; // (wide: counted when the text confirms the membership)
             s.cP += e_cnt;
             if (e_cnt > BIG_T) { s.p_n = PEND_OVF; e_cnt = 0; } // a long equal range is walked by a whole wave (match_wave.hip)
+            if (RH_ABLATE & 4) e_cnt = 0;
         }
         while (true) {
             while (e_j < e_cnt && qn < MQR) {
@@ -831,6 +838,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
     const uint64_t o0 = a.b.off ? a.b.off[rc] : rc * (uint64_t)a.b.upatl;
     const uint64_t o1 = r < n ? (a.b.off ? a.b.off[r + 1] : o0 + a.b.upatl) : o0;
     const uint32_t patl = (uint32_t)(o1 - o0);
+    const uint32_t bsh = a.b.packed ? 2u : 0u; // packed bases: four per byte, every read starts at a byte (uniform length % 4 == 0)
     const uint32_t GL = a.b.gl; // reads the wave stages at a time: GL * max_patl fits its LDS region
     const uint32_t stg_cap = stg_bytes(W, TK) - STG_PAD - 32u; // bytes of a group the region holds (skew, pad, over-read)
     // ---- bases: global -> LDS -> registers
@@ -841,12 +849,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
         const bool fits = ge >= gb && ge - gb <= stg_cap;
         wave_lds_sync();
         uint32_t l0 = 0;
-        if (fits) l0 = stage_wave(stg, a.b.bases + gb, ge - gb, lane);
+        if (fits) l0 = stage_wave(stg, a.b.bases + (gb >> bsh), (ge - gb) >> bsh, lane);
         wave_lds_sync();
         const bool in_group = lane >= g && lane < g + GL && r < n;
         if (in_group && (!fits || o1 < o0 || patl > 32u * W)) toolong = true;
-        if (in_group && fits && o1 >= o0 && patl >= a.l && patl <= 32u * W) // matchUniqueImplementation.cpp:376-394
-            elig = pack_read<W>(LdsRow{stg, l0 + (uint32_t)(o0 - gb)}, patl, s.O);
+        if (in_group && fits && o1 >= o0 && patl >= a.l && patl <= 32u * W) { // matchUniqueImplementation.cpp:376-394
+            if (a.b.packed) {
+                pack_read_packed<W>(LdsRow{stg, l0 + (uint32_t)((o0 - gb) >> 2)}, patl, s.O);
+                elig = !(a.b.nflags && ((a.b.nflags[r >> 3] >> (r & 7)) & 1)); // a read with a symbol > 3 is flagged, not packed
+            } else {
+                elig = pack_read<W>(LdsRow{stg, l0 + (uint32_t)(o0 - gb)}, patl, s.O);
+            }
+        }
     }
     if (toolong) atomicOr(a.err_flags, 1u); // the host turns this into REAL_HIP_E_INVALID / E_UNSUPPORTED
     wave_lds_sync();

@@ -142,7 +142,9 @@ __global__ __launch_bounds__(256) void match_wave_kernel(MatchArgs a)
         const uint64_t o0 = a.b.off ? a.b.off[r] : r * (uint64_t)a.b.upatl;
         const uint32_t patl = a.b.off ? (uint32_t)(a.b.off[r + 1] - o0) : a.b.upatl;
         uint64_t O[W];
-        pack_read<W>(GlobalRow{a.b.bases + o0}, patl, O); // (eligible: the matcher handed it over); the same in every lane
+        // (eligible: the matcher handed it over); the same in every lane
+        if (a.b.packed) pack_read_packed<W>(GlobalRow{a.b.bases + (o0 >> 2)}, patl, O);
+        else pack_read<W>(GlobalRow{a.b.bases + o0}, patl, O);
         const uint32_t nw = (patl + 31) >> 5;
         const uint64_t lastmask = ~0ull << (64 - 2 * (patl - 32 * (nw - 1)));
         const float eps = (float)(a.filter_mult * (double)patl); // RealOptions.hpp:74-77

@@ -444,6 +444,8 @@ struct Staged {
     const uint8_t *bases = nullptr, *qual = nullptr;
     const uint64_t *off = nullptr;
     uint32_t upatl = 0, maxpatl = 0, W = 0;
+    uint32_t packed = 0;             // the matcher reads the 2-bit packed bases itself
+    const uint8_t *nflags = nullptr;
 };
 // device buffers a host batch is copied into: the ctx's own (synchronous calls) or those of a slot (submit / wait)
 struct StageBufs {
@@ -523,7 +525,11 @@ static int stage_batch(real_hip_ctx *ctx, const real_hip_batch &b, Staged &s, co
         RH_HIP(ctx, hipEventRecord(up_done, up));
         RH_HIP(ctx, hipStreamWaitEvent(ctx->stream, up_done, 0));
     }
-    if (b.packed) {
+    if (b.packed && !b.offsets && b.patl % 4 == 0) {
+        // uniform length, a multiple of four bases: every read starts at a byte and the matcher packs its words straight
+        // from the packed bytes (25 instead of 100 bytes of HBM per 100 bp read)
+        s.bases = d_bases; s.packed = 1; s.nflags = d_flags;
+    } else if (b.packed) {
         if ((rc = rh_reserve(ctx, ctx->unpacked, (total ? total : 1) + 16))) return rc;
         if ((rc = rh_unpack_bases(ctx, d_bases, total, d_flags, s.off, s.upatl, n, (uint8_t *)ctx->unpacked.p))) return rc;
         s.bases = (const uint8_t *)ctx->unpacked.p;
@@ -548,6 +554,7 @@ static void fill_args(real_hip_ctx *ctx, const Staged &s, uint64_t n, MatchArgs 
     a.ix.fine = (uint32_t)ctx->fine;
     a.b.bases = s.bases; a.b.qual = ctx->prm.scores ? s.qual : nullptr; a.b.off = s.off;
     a.b.n_reads = n; a.b.upatl = s.upatl; a.b.W = s.W;
+    a.b.packed = s.packed; a.b.nflags = s.nflags;
     a.LL = (const double *)ctx->LL.p;
     a.counters = (unsigned long long *)ctx->counters.p;
     a.filter_mult = ctx->prm.filter_mult;

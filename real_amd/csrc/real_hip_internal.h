@@ -82,6 +82,11 @@ struct DevBatch {
     uint32_t upatl;
     uint32_t W;            // 64-bit words per oriented read = ceil(max read length / 32)
     uint32_t gl;           // reads a wave stages through its LDS region at a time (power of two <= 64)
+    // 2-bit packed bases read by the matcher itself (uniform length, a multiple of 4 bases: every read starts at a byte):
+    // bases then holds upatl / 4 bytes per read, MSB first -- the layout of a word of the oriented read; nflags (nullable):
+    // bit r%8 of byte r/8 set => read r holds a symbol > 3 and is skipped
+    uint32_t packed;
+    const uint8_t *nflags;
 };
 
 struct MatchArgs {

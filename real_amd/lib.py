@@ -13,7 +13,7 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libreal_hip.so")
+LIB_PATH = os.environ.get("REAL_HIP_LIB") or os.path.join(_HERE, "libreal_hip.so")     # (REAL_HIP_LIB: an experimental build, bench_support/ab_match.py)
 
 REAL_HIP_OK = 0
 REAL_HIP_E_INVALID = -1
