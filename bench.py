@@ -58,7 +58,7 @@ def kernel_source_hash():
     """sha256 over the sources of the match kernel: profiles/traffic.json records the hash it was measured with,
     and a figure measured on another kernel is not reported."""
     h = hashlib.sha256()
-    for f in ("match_kernel.hip", "kernel_common.h", "real_hip_internal.h"):
+    for f in ("match_kernel.hip", "match_common.h", "kernel_common.h", "real_hip_internal.h"):
         with open(os.path.join(ROOT, "real_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -339,7 +339,8 @@ def recorded_traffic(args, n):
     if not os.path.exists(tfile) or (args.patl, args.seedl, args.totalk, args.scores) != (100, 32, 3, 1) or args.shuffle_reads:
         return None, "not the profiled configuration"
     try:
-        tj = json.load(open(tfile)).get("match_unique_%dMbp_%dreads" % (int(args.genome_mbp), n), {})
+        fmt = "packed" if (args.input_format == "packed" and args.patl % 4 == 0) else "bytes"
+        tj = json.load(open(tfile)).get("match_unique_%dMbp_%dreads_%s" % (int(args.genome_mbp), n, fmt), {})
     except Exception:
         return None, "profiles/traffic.json unreadable"
     if not tj:

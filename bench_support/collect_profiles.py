@@ -12,13 +12,12 @@ rnd, pdir, bench_json = sys.argv[1], sys.argv[2], sys.argv[3]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(ROOT, "profiles")
 bench = json.loads([l for l in open(bench_json) if l.startswith("{")][-1])
-kernel_cxx = "match_kernel<%d, %s, false, %s, false>(MatchArgs)"          # W, scores, index kind; matcher proper
-W = (bench["config"]["read_len"] + 31) // 32
+W = (bench["config"]["read_len"] + 31) // 32                # match_kernel<W, scores, all, table kind>: the lane-per-read matcher
 kname = None
 stats = os.path.join(pdir, "trace", "trace_kernel_stats.csv")
 rows = list(csv.DictReader(open(stats)))
 for r in rows:
-    if r["Name"].startswith("void match_kernel<%d," % W) and r["Name"].rstrip().endswith("false>(MatchArgs)"):
+    if r["Name"].startswith("void match_kernel<%d, true, false," % W):
         kname = r["Name"]
         avg_ms = float(r["AverageNs"]) / 1e6
         calls = int(r["Calls"])
@@ -39,9 +38,12 @@ for f in glob.glob(os.path.join(pdir, "*", "*_counter_collection.csv")):
             pmc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 avg = {k: sum(v) / len(v) for k, v in pmc.items()}
 hbm = 2 * avg["FETCH_SIZE"] * 1024 + avg["WRITE_SIZE"] * 1024
-key = "match_unique_%dMbp_%dreads" % (bench["config"]["genome_bp"] // 1_000_000, bench["config"]["reads_per_gpu_per_step"])
+sys.path.insert(0, ROOT)
+import bench as bench_py
+fmt = "packed" if bench["config"].get("input_format", "").startswith("2-bit") else "bytes"
+key = "match_unique_%dMbp_%dreads_%s" % (bench["config"]["genome_bp"] // 1_000_000, bench["config"]["reads_per_gpu_per_step"], fmt)
 tj = {key: {
-    "hbm_bytes_per_launch": hbm, "kernel": sel, "round": int(rnd.lstrip("r")),
+    "hbm_bytes_per_launch": hbm, "kernel": sel, "round": int(rnd.lstrip("r")), "kernel_source_sha": bench_py.kernel_source_hash(),
     "FETCH_SIZE_KiB_per_launch": avg["FETCH_SIZE"], "WRITE_SIZE_KiB_per_launch": avg["WRITE_SIZE"],
     "correction": "reads = 2 x FETCH_SIZE x 1024 (gfx950: requests tallied at 64 B, L2 lines are 128 B; MI355X_MICROARCH.md "
                   "section HBM), writes = WRITE_SIZE x 1024; separate --pmc passes (bench_support/profile.sh)",
