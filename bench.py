@@ -151,8 +151,8 @@ def gen_reads(torch, sym, n_reads, patl, errprob, seed, device, shuffle=False):
 def pack_bases(torch, bases, n_reads, patl):
     """one symbol per byte -> 2 bits per base, four per byte, MSB first (real_hip_batch.packed; the reads of the workload
     hold no N).  What the matcher reads from HBM per 100 bp read drops from 100 to 25 bytes of bases."""
-    assert patl % 4 == 0
-    q4 = bases.view(n_reads * (patl // 4), 4)
+    assert (n_reads * patl) % 4 == 0          # (a read may start inside a byte: 150 bp reads alternate)
+    q4 = bases.view(n_reads * patl // 4, 4)
     return ((q4[:, 0] << 6) | (q4[:, 1] << 4) | (q4[:, 2] << 2) | q4[:, 3]).to(torch.uint8)
 
 
@@ -339,7 +339,7 @@ def recorded_traffic(args, n):
     if not os.path.exists(tfile) or (args.patl, args.seedl, args.totalk, args.scores) != (100, 32, 3, 1) or args.shuffle_reads:
         return None, "not the profiled configuration"
     try:
-        fmt = "packed" if (args.input_format == "packed" and args.patl % 4 == 0) else "bytes"
+        fmt = "packed" if (args.input_format == "packed" and (n * args.patl) % 4 == 0) else "bytes"
         tj = json.load(open(tfile)).get("match_unique_%dMbp_%dreads_%s" % (int(args.genome_mbp), n, fmt), {})
     except Exception:
         return None, "profiles/traffic.json unreadable"
@@ -490,7 +490,7 @@ def main():
         return
 
     # ---- the headline: C2 (or C4 = N x C2)
-    packed = args.input_format == "packed" and args.patl % 4 == 0
+    packed = args.input_format == "packed" and (n * args.patl) % 4 == 0
     pk = pack_bases(torch, bases, n, args.patl) if packed else None
     dt, ctr, (match_ms, match_n), (rep_ms, rep_n), (info, score) = timed_unique(
         torch, dist, m, rlib, pk if packed else bases, qual, args.patl, n, args.steps, args.warmup, world, rank, dev, gather_dev, log, packed=packed)
@@ -518,7 +518,7 @@ def main():
                        "genome_bp": G, "reads_per_gpu_per_step": n, "read_len": args.patl, "seedl": args.seedl,
                        "seedkmax": 2, "totalkmax": args.totalk, "scores": bool(args.scores), "errprob": 0.02,
                        "read_order": "shuffled" if args.shuffle_reads else "sorted by position (genpat.cpp:99)",
-                       "input_format": ("2-bit packed bases (25 B per 100 bp read) + one quality byte per base, resident in HBM" if packed
+                       "input_format": ("2-bit packed bases (%g B per %d bp read) + one quality byte per base, resident in HBM" % (args.patl / 4, args.patl) if packed
                                         else "one mapped symbol per byte + one quality byte per base, resident in HBM"),
                        "index_entries": n_entries, "prefix_bits": m.prefix_bits, "bucket_tables": TABLE_KINDS[m.table_kind],
                        "parallelism": "reads sharded x%d, index replicated, one RCCL gather of records" % world,
@@ -562,7 +562,7 @@ def extras(torch, dist, rlib, args, m, opts, cpu, sym, sym_host, frag, reads, n,
 
     # (0) the same step from the other resident input format
     try:
-        other_packed = pk is None and patl % 4 == 0
+        other_packed = pk is None and (n * patl) % 4 == 0
         ob = pack_bases(torch, bases, n, patl) if other_packed else bases
         dt, ctr, (ms, ln), (rms, rn), _ = timed_unique(torch, dist, m, rlib, ob, qual, patl, n, K, 1, 1, 0, dev, dev, packed=other_packed)
         ex["c2_packed_bases" if other_packed else "c2_byte_bases"] = {
@@ -648,11 +648,14 @@ def extras(torch, dist, rlib, args, m, opts, cpu, sym, sym_host, frag, reads, n,
         t_ix5 = time.time() - t0
         ibs5 = m5.index_build_stats()
         b5, q5, pos5, inv5 = gen_reads(torch, sym, n, 150, 0.02, 12, dev)
-        dt, ctr, (ms, ln), (rms, rn), (info5, score5) = timed_unique(torch, dist, m5, rlib, b5, q5, 150, n, K, 1, 1, 0, dev, dev)
+        p5 = pk is not None and (n * 150) % 4 == 0
+        dt, ctr, (ms, ln), (rms, rn), (info5, score5) = timed_unique(torch, dist, m5, rlib, pack_bases(torch, b5, n, 150) if p5 else b5, q5, 150, n, K, 1, 1, 0,
+                                                                     dev, dev, packed=p5)
         st = (info5 >> 61) & 7
         al = ((st == 1) | (st == 2))
         c5 = {"workload": "matchUnique, %dM synthetic 150 bp reads vs %.0f Mbp genome, seedl 64 (64-bit signatures), k=5, scores on (BASELINE configs[4])" % (n // 1_000_000, args.genome_mbp),
               "ms_per_step": dt / K * 1e3, "reads_per_s": n * K / dt, "uniquely_aligned_frac": float(al.float().mean().item()),
+              "input_format": "2-bit packed bases" if p5 else "one symbol per byte",
               "index_build_s": t_ix5, "index_build_kernel_s": ibs5["kernel_ms"] / 1e3, "index_build_hipMalloc_s": ibs5["alloc_ms"] / 1e3,
               "index_build_hipFree_s": ibs5["free_ms"] / 1e3, "bucket_tables": TABLE_KINDS[m5.table_kind], "prefix_bits": m5.prefix_bits,
               "roofline": roofline_block(ctr, ms, ln, 150, 64, True, "match_kernel<W=5,scores=1,unique,tables=%s>" % TABLE_KINDS[m5.table_kind]),

@@ -77,21 +77,24 @@ __device__ __forceinline__ bool pack_read(const Row &row, uint32_t patl, uint64_
     return ok;
 }
 
-// the same from 2-bit packed bases (4 per byte, MSB first = the byte order of a word of the read read big-endian);
-// patl is a multiple of 4
+// the same from 2-bit packed bases: base g of the batch at bits 7-2(g%4)-1.. of byte g/4 (MSB first = the byte order of a
+// word of the read, read big-endian).  row = the bytes from the one that holds the read's first base on; skew = that
+// base's index inside its byte (0..3): the words are shifted left by 2*skew bits, the next byte fills in from the right.
 template <int W, class Row>
-__device__ __forceinline__ void pack_read_packed(const Row &row, uint32_t patl, uint64_t *O)
+__device__ __forceinline__ void pack_read_packed(const Row &row, uint32_t patl, uint32_t skew, uint64_t *O)
 {
-    const uint32_t nbytes = patl >> 2;
+    const uint32_t nbytes = (skew + patl + 3) >> 2; // bytes that hold a base of this read
+    const uint32_t nw = (patl + 31) >> 5, sh = 2 * skew;
 #pragma unroll
     for (int j = 0; j < W; ++j) {
         uint64_t w = 0;
-        if (8u * j < nbytes) {
+        if ((uint32_t)j < nw) {
             const uint32_t hi = __builtin_bswap32(row.dword(8 * j, nbytes));
-            const uint32_t lo = (8u * j + 4 < nbytes) ? __builtin_bswap32(row.dword(8 * j + 4, nbytes)) : 0u;
+            const uint32_t lo = __builtin_bswap32(row.dword(8 * j + 4, nbytes));
             w = ((uint64_t)hi << 32) | lo;
-            const uint32_t rem = nbytes - 8u * j; // bytes of this word that belong to the read
-            if (rem < 8) w &= ~0ull << (64 - 8 * rem);
+            if (sh) w = (w << sh) | ((uint64_t)(row.dword(8 * j + 8, nbytes) & 0xffu) >> (8 - sh));
+            const uint32_t rem = patl - 32u * j; // bases of this word that belong to the read
+            if (rem < 32) w &= ~0ull << (64 - 2 * rem);
         }
         O[j] = w;
     }

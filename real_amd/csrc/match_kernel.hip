@@ -838,7 +838,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
     const uint64_t o0 = a.b.off ? a.b.off[rc] : rc * (uint64_t)a.b.upatl;
     const uint64_t o1 = r < n ? (a.b.off ? a.b.off[r + 1] : o0 + a.b.upatl) : o0;
     const uint32_t patl = (uint32_t)(o1 - o0);
-    const uint32_t bsh = a.b.packed ? 2u : 0u; // packed bases: four per byte, every read starts at a byte (uniform length % 4 == 0)
+    const uint32_t bsh = a.b.packed ? 2u : 0u; // packed bases: four per byte
     const uint32_t GL = a.b.gl; // reads the wave stages at a time: GL * max_patl fits its LDS region
     const uint32_t stg_cap = stg_bytes(W, TK) - STG_PAD - 32u; // bytes of a group the region holds (skew, pad, over-read)
     // ---- bases: global -> LDS -> registers
@@ -849,13 +849,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
         const bool fits = ge >= gb && ge - gb <= stg_cap;
         wave_lds_sync();
         uint32_t l0 = 0;
-        if (fits) l0 = stage_wave(stg, a.b.bases + (gb >> bsh), (ge - gb) >> bsh, lane);
+        if (fits) l0 = stage_wave(stg, a.b.bases + (gb >> bsh), a.b.packed ? ((ge + 3) >> 2) - (gb >> 2) : ge - gb, lane);
         wave_lds_sync();
         const bool in_group = lane >= g && lane < g + GL && r < n;
         if (in_group && (!fits || o1 < o0 || patl > 32u * W)) toolong = true;
         if (in_group && fits && o1 >= o0 && patl >= a.l && patl <= 32u * W) { // matchUniqueImplementation.cpp:376-394
             if (a.b.packed) {
-                pack_read_packed<W>(LdsRow{stg, l0 + (uint32_t)((o0 - gb) >> 2)}, patl, s.O);
+                pack_read_packed<W>(LdsRow{stg, l0 + (uint32_t)((o0 >> 2) - (gb >> 2))}, patl, (uint32_t)o0 & 3u, s.O);
                 elig = !(a.b.nflags && ((a.b.nflags[r >> 3] >> (r & 7)) & 1)); // a read with a symbol > 3 is flagged, not packed
             } else {
                 elig = pack_read<W>(LdsRow{stg, l0 + (uint32_t)(o0 - gb)}, patl, s.O);

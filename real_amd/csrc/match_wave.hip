@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void match_wave_kernel(MatchArgs a)
         const uint32_t patl = a.b.off ? (uint32_t)(a.b.off[r + 1] - o0) : a.b.upatl;
         uint64_t O[W];
         // (eligible: the matcher handed it over); the same in every lane
-        if (a.b.packed) pack_read_packed<W>(GlobalRow{a.b.bases + (o0 >> 2)}, patl, O);
+        if (a.b.packed) pack_read_packed<W>(GlobalRow{a.b.bases + (o0 >> 2)}, patl, (uint32_t)o0 & 3u, O);
         else pack_read<W>(GlobalRow{a.b.bases + o0}, patl, O);
         const uint32_t nw = (patl + 31) >> 5;
         const uint64_t lastmask = ~0ull << (64 - 2 * (patl - 32 * (nw - 1)));

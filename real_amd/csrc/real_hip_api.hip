@@ -213,7 +213,7 @@ extern "C" void real_hip_destroy(real_hip_ctx *c)
     DevBuf *all[] = {&c->comm_counts, &c->comm_scratch, &c->text, &c->wild, &c->frag, &c->LL, &c->counters, &c->s_bases, &c->s_qual, &c->s_off, &c->s_info,
                      &c->s_score, &c->maxpatl, &c->ovf_list, &c->ovf_count, &c->raw, &c->raw_count, &c->hit_cnt, &c->big_list, &c->p_text, &c->p_nl, &c->p_scal, &c->p_spans, &c->p_off,
                      &c->p_len1, &c->p_bases, &c->p_qual, &c->keys_a,
-                     &c->keys_b, &c->vals_a, &c->vals_b, &c->sort_tmp, &c->hit_off, &c->s_hits, &c->s_nflags, &c->unpacked};
+                     &c->keys_b, &c->vals_a, &c->vals_b, &c->sort_tmp, &c->hit_off, &c->s_hits, &c->s_nflags};
     for (DevBuf *b : all) rh_release(*b);
     for (int k = 0; k < 6; ++k) { rh_release(c->ent[k]); rh_release(c->bkt[k]); }
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
@@ -463,8 +463,8 @@ static int batch_view(real_hip_ctx *ctx, const real_hip_batch *b, real_hip_batch
     return REAL_HIP_OK;
 }
 
-// Uploads (host batches; on `up`, which is ctx->stream for the synchronous calls and the copy stream for submitted ones)
-// and, on ctx->stream, unpacks 2-bit packed bases.  After it the arrays of `s` are valid for kernels on ctx->stream.
+// Uploads (host batches; on `up`, which is ctx->stream for the synchronous calls and the copy stream for submitted ones).
+// After it the arrays of `s` are valid for kernels on ctx->stream.
 static int stage_batch(real_hip_ctx *ctx, const real_hip_batch &b, Staged &s, const StageBufs &sb, hipStream_t up, hipEvent_t up_done)
 {
     if (!ctx->have_text || !ctx->have_index) return rh_fail(ctx, REAL_HIP_E_STATE, "text and index must be set", hipSuccess);
@@ -480,10 +480,6 @@ static int stage_batch(real_hip_ctx *ctx, const real_hip_batch &b, Staged &s, co
             s.off = b.offsets;
             s.maxpatl = b.max_patl;
             if (!s.maxpatl && (rc = rh_max_patl(ctx, s.off, n, &s.maxpatl))) return rc;
-            if (b.packed) { // symbols of the batch = its last offset
-                RH_HIP(ctx, hipMemcpyAsync(&total, s.off + n, 8, hipMemcpyDeviceToHost, ctx->stream));
-                RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            }
         } else {
             for (uint64_t i = 0; i < n; ++i) {
                 if (b.offsets[i + 1] < b.offsets[i]) return rh_fail(ctx, REAL_HIP_E_INVALID, "offsets not monotone", hipSuccess);
@@ -525,14 +521,10 @@ static int stage_batch(real_hip_ctx *ctx, const real_hip_batch &b, Staged &s, co
         RH_HIP(ctx, hipEventRecord(up_done, up));
         RH_HIP(ctx, hipStreamWaitEvent(ctx->stream, up_done, 0));
     }
-    if (b.packed && !b.offsets && b.patl % 4 == 0) {
-        // uniform length, a multiple of four bases: every read starts at a byte and the matcher packs its words straight
-        // from the packed bytes (25 instead of 100 bytes of HBM per 100 bp read)
+    if (b.packed) {
+        // the matcher packs its words straight from the packed bytes (25 instead of 100 bytes of HBM per 100 bp read);
+        // a read may start anywhere inside a byte
         s.bases = d_bases; s.packed = 1; s.nflags = d_flags;
-    } else if (b.packed) {
-        if ((rc = rh_reserve(ctx, ctx->unpacked, (total ? total : 1) + 16))) return rc;
-        if ((rc = rh_unpack_bases(ctx, d_bases, total, d_flags, s.off, s.upatl, n, (uint8_t *)ctx->unpacked.p))) return rc;
-        s.bases = (const uint8_t *)ctx->unpacked.p;
     } else {
         s.bases = d_bases;
     }

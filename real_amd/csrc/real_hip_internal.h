@@ -82,9 +82,9 @@ struct DevBatch {
     uint32_t upatl;
     uint32_t W;            // 64-bit words per oriented read = ceil(max read length / 32)
     uint32_t gl;           // reads a wave stages through its LDS region at a time (power of two <= 64)
-    // 2-bit packed bases read by the matcher itself (uniform length, a multiple of 4 bases: every read starts at a byte):
-    // bases then holds upatl / 4 bytes per read, MSB first -- the layout of a word of the oriented read; nflags (nullable):
-    // bit r%8 of byte r/8 set => read r holds a symbol > 3 and is skipped
+    // 2-bit packed bases: base g of the batch at bits 7-2(g%4)-1.. of byte g/4, MSB first -- the layout of a word of the
+    // oriented read; a read may start inside a byte.  nflags (nullable): bit r%8 of byte r/8 set => read r holds a symbol
+    // > 3 and is skipped
     uint32_t packed;
     const uint8_t *nflags;
 };
@@ -151,7 +151,6 @@ struct real_hip_ctx {
 
     // batch staging (host batches), hand-over list of the repeat kernel
     DevBuf s_bases, s_qual, s_off, s_info, s_score, s_nflags;
-    DevBuf unpacked;                                // byte symbols of a 2-bit packed batch (one batch at a time: the kernels of a ctx run in order)
     RhSlot slot[REAL_HIP_SLOTS];                    // submit / wait
     hipStream_t copy_stream = nullptr, down_stream = nullptr;
     int time_slot = -1;
@@ -213,8 +212,7 @@ struct RhTimer { // HIP events on the ctx stream around a group of launches
 void rh_comm_destroy(real_hip_ctx *ctx);
 int rh_launch_match(real_hip_ctx *ctx, const MatchArgs &a, bool all, int state_slot);
 int rh_match_finish(real_hip_ctx *ctx, int state_slot); // after the launch has completed: errors the kernels flagged
-int rh_unpack_bases(real_hip_ctx *ctx, const uint8_t *d_packed, uint64_t n_symbols, const uint8_t *d_nflags, const uint64_t *d_off,
-                    uint32_t upatl, uint64_t n_reads, uint8_t *d_out);
+
 // asynchronous kernel timing (no host synchronisation at the launch site)
 void rh_time_begin(real_hip_ctx *ctx, hipStream_t st, int which);
 void rh_time_end(real_hip_ctx *ctx, hipStream_t st);
