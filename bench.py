@@ -267,7 +267,7 @@ def timed_unique(torch, dist, m, rlib, bases, qual, patl, n, steps, warmup, worl
     return dt, m.counters(), m.kernel_time(rlib.K_MATCH_UNIQUE), m.kernel_time(rlib.K_MATCH_REPEAT), bufs[last[0]]
 
 
-def timed_all(torch, dist, m, rlib, bases, qual, patl, n, steps, warmup, world, rank, dev, gather_dev):
+def timed_all(torch, dist, m, rlib, bases, qual, patl, n, steps, warmup, world, rank, dev, gather_dev, packed=False):
     """K steps of matchAll into device buffers; N > 1: the variable-length hit lists are gathered to the root every
     step (counts first, then payload).  Returns (seconds, counters, kernel times, hits per step on this rank,
     hits on the root per step)."""
@@ -281,6 +281,7 @@ def timed_all(torch, dist, m, rlib, bases, qual, patl, n, steps, warmup, world, 
 
     def step():
         b = m._batch(bases, qual, None, patl, n)
+        b.packed = int(bool(packed))
         nout = C.c_uint64(0)
         m.sync_inputs(bases)
         rc = m._L.real_hip_match_all(m._h, C.byref(b), hits_dev.data_ptr(), cap, C.byref(nout), hoff_dev.data_ptr())
@@ -468,7 +469,9 @@ def main():
         return
 
     if args.mode == "all":
-        dt, ctr, kt, nh, nroot, _ = timed_all(torch, dist, m, rlib, bases, qual, args.patl, n, args.steps, args.warmup, world, rank, dev, gather_dev)
+        packed = args.input_format == "packed" and (n * args.patl) % 4 == 0
+        dt, ctr, kt, nh, nroot, _ = timed_all(torch, dist, m, rlib, pack_bases(torch, bases, n, args.patl) if packed else bases, qual, args.patl, n,
+                                              args.steps, args.warmup, world, rank, dev, gather_dev, packed=packed)
         if rank == 0:
             K = args.steps
             mk, ml = kt["match"]
@@ -601,10 +604,12 @@ def extras(torch, dist, rlib, args, m, opts, cpu, sym, sym_host, frag, reads, n,
     # (3) C3: matchAll, k=2, the same index and reads
     try:
         m.set_match_params(totalkmax=2)
-        dt, ctr, kt, nh, _, (hits_dev, hoff_dev) = timed_all(torch, dist, m, rlib, bases, qual, patl, n, K, 1, 1, 0, dev, dev)
+        dt, ctr, kt, nh, _, (hits_dev, hoff_dev) = timed_all(torch, dist, m, rlib, pk if pk is not None else bases, qual, patl, n, K, 1, 1, 0, dev, dev,
+                                                             packed=pk is not None)
         mk, ml = kt["match"]
         c3 = {"workload": "matchAll, %dM synthetic %d bp reads vs %.0f Mbp genome, k=2, scores on (BASELINE configs[2])" % (n // 1_000_000, patl, args.genome_mbp),
               "ms_per_step": dt / K * 1e3, "reads_per_s": n * K / dt, "hits_per_step": nh,
+              "input_format": "2-bit packed bases" if pk is not None else "one symbol per byte",
               "order_pass_avg_ms": kt["order"][0] / max(kt["order"][1], 1),
               "roofline": roofline_block(ctr, mk, ml, patl, args.seedl, True,
                                          "match_kernel<W=%d,scores=1,all,tables=%s>" % ((patl + 31) // 32, TABLE_KINDS[m.table_kind]),
