@@ -118,6 +118,11 @@ __device__ __forceinline__ void seed_halves(const uint64_t *O, uint32_t l, uint6
 // starting at 1.0, cast to float once.  Ow = oriented read, tw = text aligned to the read, qrow = the
 // read's qualities as given (oriented here: base i of the reversed read has quality[patl-1-i],
 // Pattern.hpp:105-128); no qualities => 30 (Pattern.hpp:42-45).
+// sLL holds the 1024 table entries and, behind them, one 0.0 (RH_LL_ZERO): positions behind the end of the read
+// add that instead of being branched around -- x + 0.0 is x, the chain of sums is the reference's -- so that the
+// sixteen positions of a step are straight-line code: eight table reads in flight, then their eight adds in order.
+#define RH_LL_ZERO 1024u
+#define RH_LL_SLOTS 1025u
 template <int W, class Row>
 __device__ __forceinline__ float score_location(const double *sLL, const uint64_t *Ow, const uint64_t *tw, uint32_t patl,
                                                 const Row &qrow, bool has_q, uint32_t inv)
@@ -151,17 +156,22 @@ __device__ __forceinline__ float score_location(const double *sLL, const uint64_
         const uint32_t lim = min(16u, patl - 16u * c);
         const uint32_t tr = th[0], rr = oh[0];
 #pragma unroll
-        for (uint32_t u = 0; u < 16; ++u) {
-            if (u < lim) {
+        for (int h = 0; h < 2; ++h) {
+            double x[8];
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                const uint32_t u = 8u * h + v;
                 const uint32_t ref = (tr >> (30 - 2 * u)) & 3;
                 const uint32_t rb = (rr >> (30 - 2 * u)) & 3;
                 const uint32_t q = (qa[u >> 2] >> (8 * (u & 3))) & 0xff;
-                raw += sLL[((ref << 8) | (rb << 6) | q) & 1023];
+                const uint32_t idx = ((ref << 8) | (rb << 6) | q) & 1023;
+                x[v] = sLL[u < lim ? idx : RH_LL_ZERO];
             }
+#pragma unroll
+            for (int v = 0; v < 8; ++v) raw += x[v];
         }
 #pragma unroll
         for (int i = 0; i + 1 < NQ; ++i) { th[i] = th[i + 1]; oh[i] = oh[i + 1]; }
     }
     return (float)raw;
 }
-

@@ -817,10 +817,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
 {
     constexpr bool FINE = TK != 0;
     constexpr bool DEFER = SCORES || ALL;
-    __shared__ double sLL[SCORES ? 1024 : 1];
+    __shared__ double sLL[SCORES ? RH_LL_SLOTS : 1];
     __shared__ __attribute__((aligned(16))) uint8_t smem[4 * stg_bytes(W, TK)];
     if (SCORES) {
         for (int i = threadIdx.x; i < 1024; i += 256) sLL[i] = a.LL[i];
+        if (threadIdx.x == 0) sLL[RH_LL_ZERO] = 0.0;
         __syncthreads();
     }
     const uint32_t lane = threadIdx.x & 63;

@@ -124,9 +124,10 @@ template <bool SCORES, bool ALL>
 __global__ __launch_bounds__(256) void match_wave_kernel(MatchArgs a)
 {
     constexpr int W = WV_W;
-    __shared__ double sLL[SCORES ? 1024 : 1];
+    __shared__ double sLL[SCORES ? RH_LL_SLOTS : 1];
     if (SCORES) {
         for (int i = threadIdx.x; i < 1024; i += 256) sLL[i] = a.LL[i];
+        if (threadIdx.x == 0) sLL[RH_LL_ZERO] = 0.0;
         __syncthreads();
     }
     const uint32_t lane = threadIdx.x & 63;
