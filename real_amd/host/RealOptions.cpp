@@ -76,6 +76,7 @@ RealOptions::RealOptions(int argc, char *argv[])
         else if (a == "-filter_level") { filter_level = atoi(need("-filter_level").c_str()); i += 2; }
         else if (a == "-device") { device = atoi(need("-device").c_str()); i += 2; }
         else if (a == "-gpus") { gpus = atoi(need("-gpus").c_str()); i += 2; }
+        else if (a == "-gpus_share_device") { gpus_share_device = atoi(need("-gpus_share_device").c_str()) != 0; i += 2; }
         else if (a == "-index") { host_index = (need("-index") == "host"); i += 2; }
         else if (a == "-block") { block_entries = strtoull(need("-block").c_str(), 0, 10); i += 2; }
         else if (a == "-batch") { batch_reads = strtoull(need("-batch").c_str(), 0, 10); i += 2; }

@@ -24,6 +24,7 @@ struct RealOptions {
     // this build
     int device = 0;           // -device: first HIP device
     int gpus = 1;             // -gpus: read batches are dealt round-robin to this many devices
+    bool gpus_share_device = false; // -gpus_share_device 1: the contexts of -gpus N all sit on -device (rehearsal of the N-context paths on a one-GPU box)
     bool host_index = false;  // -index host|device: where the six lists are sorted
     uint64_t block_entries = 0; // -block: positions per index block (0 = as many as fit)
     uint64_t batch_reads = 4u << 20; // -batch: reads per device batch

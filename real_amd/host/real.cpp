@@ -77,7 +77,7 @@ CtxVec makeContexts(const RealOptions &o)
     real_hip_scoring_table(o.similarity, o.gc, o.trans, o.err, o.gcmut_bias, p.LL); // Scoring(opts...) :1115
     CtxVec v;
     for (int g = 0; g < o.gpus; ++g) {
-        p.device = o.device + g;
+        p.device = o.gpus_share_device ? o.device : o.device + g;
         std::unique_ptr<Ctx> c(new Ctx);
         check(nullptr, real_hip_create(&c->h, &p), "real_hip_create (is an MI355X visible? there is no CPU fallback)");
         v.push_back(std::move(c));
@@ -612,45 +612,66 @@ int matchAll(const RealOptions &o)
             T.index += now_s() - t0;
             if (!n) break;
             first += n;
-            ReadReader rr(o.patternfilename, o.fastq, qoff);
-            std::vector<ReadBlock> blk(ctx.size());
             std::vector<std::vector<real_hip_hit>> hits(ctx.size(), std::vector<real_hip_hit>(1u << 20));
             std::vector<std::vector<uint64_t>> hoff(ctx.size());
-            n_reads = 0;
-            while (true) {
-                size_t used = 0;
-                t0 = now_s();
-                for (; used < ctx.size(); ++used)
-                    if (!rr.fillBlock(blk[used], o.batch_reads, true)) break;
-                T.parse += now_s() - t0;
-                if (!used) break;
-                t0 = now_s();
-                onEach(used, [&](size_t g) {
-                    real_hip_batch rb = makeBatch(blk[g]);
-                    hoff[g].assign(blk[g].size() + 1, 0);
-                    uint64_t nh = 0;
-                    int rc = real_hip_match_all(ctx[g]->h, &rb, hits[g].data(), hits[g].size(), &nh, hoff[g].data());
-                    if (rc == REAL_HIP_E_OVERFLOW) { // retry with the size the library reports
-                        hits[g].resize(nh + 16);
-                        rc = real_hip_match_all(ctx[g]->h, &rb, hits[g].data(), hits[g].size(), &nh, hoff[g].data());
-                    }
-                    check(ctx[g]->h, rc, "real_hip_match_all");
-                });
-                T.match += now_s() - t0;
-                for (size_t g = 0; g < used; ++g) {
-                    const ReadBlock &b = blk[g];
-                    n_reads += b.size();
-                    n_lines += hoff[g][b.size()];
-                    formatAndWrite(b.size(), out, T, [&](uint64_t i, std::string &s) {
-                        const uint64_t lo = b.offsets[i], patl = b.offsets[i + 1] - lo;
-                        for (uint64_t k = hoff[g][i]; k < hoff[g][i + 1]; ++k) {
-                            const real_hip_hit &M = hits[g][k];
-                            appendLine(s, b.ids[i].data(), b.ids[i].size(), nullptr, &b.bases[lo], patl, o.scores, M.score, M.inverted != 0,
-                                       R.G.frag_names[M.frag], (uint64_t)M.pos - R.G.frag_start[M.frag] + 1, M.k);
-                        }
-                    });
+            auto matchOne = [&](size_t g, real_hip_batch rb) {
+                hoff[g].assign(rb.n_reads + 1, 0);
+                if (!rb.n_reads) return;
+                uint64_t nh = 0;
+                int rc = real_hip_match_all(ctx[g]->h, &rb, hits[g].data(), hits[g].size(), &nh, hoff[g].data());
+                if (rc == REAL_HIP_E_OVERFLOW) { // retry with the size the library reports
+                    hits[g].resize(nh + 16);
+                    rc = real_hip_match_all(ctx[g]->h, &rb, hits[g].data(), hits[g].size(), &nh, hoff[g].data());
                 }
-            }
+                check(ctx[g]->h, rc, "real_hip_match_all");
+            };
+            std::vector<uint32_t> id_start, id_len;
+            std::vector<uint64_t> off;
+            n_reads = streamReads(o, ctx, qoff, true, T,
+                [&](const std::vector<uint64_t> &, const std::vector<Chunk> &ch, const std::vector<real_hip_parsed> &pr) {
+                    const double tm = now_s();
+                    onEach(ch.size(), [&](size_t g) { matchOne(g, makeBatch(pr[g])); });
+                    T.match += now_s() - tm;
+                    for (size_t g = 0; g < ch.size(); ++g) { // (in file order)
+                        const uint64_t n = pr[g].n_reads;
+                        if (!n) continue;
+                        id_start.resize(n); id_len.resize(n); off.resize(n + 1);
+                        const double td = now_s();
+                        check(ctx[g]->h, real_hip_download(ctx[g]->h, pr[g].id_start, id_start.data(), n * 4), "real_hip_download");
+                        check(ctx[g]->h, real_hip_download(ctx[g]->h, pr[g].id_len, id_len.data(), n * 4), "real_hip_download");
+                        check(ctx[g]->h, real_hip_download(ctx[g]->h, pr[g].offsets, off.data(), (n + 1) * 8), "real_hip_download");
+                        T.parse += now_s() - td;
+                        const char *text = ch[g].text;
+                        n_lines += hoff[g][n];
+                        formatAndWrite(n, out, T, [&](uint64_t i, std::string &s) {
+                            uint64_t il = id_len[i];
+                            if (text[id_start[i] + il] == '\r') il++;
+                            const uint64_t patl = off[i + 1] - off[i];
+                            for (uint64_t k = hoff[g][i]; k < hoff[g][i + 1]; ++k) {
+                                const real_hip_hit &M = hits[g][k];
+                                appendLine(s, text + id_start[i], il, text + id_start[i] + il + 1, nullptr, patl, o.scores, M.score, M.inverted != 0,
+                                           R.G.frag_names[M.frag], (uint64_t)M.pos - R.G.frag_start[M.frag] + 1, M.k);
+                            }
+                        });
+                    }
+                },
+                [&](std::vector<ReadBlock> &blk, size_t used) {
+                    const double tm = now_s();
+                    onEach(used, [&](size_t g) { matchOne(g, makeBatch(blk[g])); });
+                    T.match += now_s() - tm;
+                    for (size_t g = 0; g < used; ++g) {
+                        const ReadBlock &b = blk[g];
+                        n_lines += hoff[g][b.size()];
+                        formatAndWrite(b.size(), out, T, [&](uint64_t i, std::string &s) {
+                            const uint64_t lo = b.offsets[i], patl = b.offsets[i + 1] - lo;
+                            for (uint64_t k = hoff[g][i]; k < hoff[g][i + 1]; ++k) {
+                                const real_hip_hit &M = hits[g][k];
+                                appendLine(s, b.ids[i].data(), b.ids[i].size(), nullptr, &b.bases[lo], patl, o.scores, M.score, M.inverted != 0,
+                                           R.G.frag_names[M.frag], (uint64_t)M.pos - R.G.frag_start[M.frag] + 1, M.k);
+                            }
+                        });
+                    }
+                });
         }
     }
     if (fflush(out) != 0) throw std::runtime_error("write to the output file failed");

@@ -69,6 +69,8 @@ def oracle_unique(ora, g, b, seedl, seedk, totalk, scores, n_list=0, fasta=False
     (1, ["-gpuparse", "0"], 0, True),                              # read file parsed by the host reader
     (1, ["-table_kind", "3", "-l", "16", "-prefix_bits", "13"], 0, True),   # bucket rows (seed length 16 so that they are small)
     (1, ["-wrap"], 0, False),                                      # wrapped FASTA: the device parser refuses, host reader takes over
+    (1, ["-gpus", "2", "-gpus_share_device", "1", "-chunk", "40000"], 0, True),          # two contexts (on the one device here): chunks dealt to them in turn
+    (1, ["-gpus", "3", "-gpus_share_device", "1", "-gpuparse", "0", "-batch", "200"], 0, True),   # three contexts fed by the host reader
 ])
 def test_real_cli_match_unique(ora, tmp_path, scores, extra, n_list, fastq):
     g = synth.random_genome(80_000, seed=41, n_frag=3, n_runs=6, repeats=15)
@@ -92,12 +94,13 @@ def test_real_cli_match_unique(ora, tmp_path, scores, extra, n_list, fastq):
     assert ("unique: %d" % len(want)) in r.stderr.decode()
 
 
-def test_real_cli_match_all(ora, tmp_path):
+@pytest.mark.parametrize("extra", [[], ["-gpus", "2", "-gpus_share_device", "1", "-batch", "150"]])
+def test_real_cli_match_all(ora, tmp_path, extra):
     g = synth.random_genome(60_000, seed=51, n_frag=2, repeats=25, repeat_len=200)
     b = synth.sample_reads(g, 800, 100, 0.01, seed=52)
     fa, rd = write_inputs(tmp_path, g, b, True)
     out = str(tmp_path / "all.tsv")
-    r = subprocess.run([REAL, "-t", fa, "-p", rd, "-o", out, "-u", "0", "-e", "2", "-s", "2", "-l", "32", "-q", "1"],
+    r = subprocess.run([REAL, "-t", fa, "-p", rd, "-o", out, "-u", "0", "-e", "2", "-s", "2", "-l", "32", "-q", "1"] + extra,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     og = ora.Genome(g.sym, g.frag_start)
