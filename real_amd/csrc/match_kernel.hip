@@ -50,6 +50,9 @@ __host__ __device__ constexpr uint32_t stg_bytes(int W, int TK) { return TK >= 3
 #define BKX_OFF (ROWBUF_OFF + 64u * 128u) /* 64 bucket numbers, transposed for the piece loaders */
 static_assert(BKX_OFF + 256u <= stg_bytes(4, 3) && ROWBUF_OFF % 16 == 0 && QUEUE_BYTES % 16 == 0, "row staging fits the wave's LDS region");
 #define STG_PAD 16u
+#ifndef RH_KEEP_TW_MAXW
+#define RH_KEEP_TW_MAXW 4
+#endif
 #define NPEND 2      // verified locations a lane parks until their scores are computed (flush_pending)
 #define PEND_EV 32   // update() events parked with them
 #define SLOT_NONE 3u
@@ -78,7 +81,8 @@ struct LaneState {
     // SCORES: verified locations whose score is still to be computed, and the update() events that refer
     // to them, in event order (see flush_pending)
     uint32_t p_pos[NPEND], p_meta[NPEND]; // text position; k | strand << 8 | fragment << 16
-    uint64_t p_tw[W];                     // aligned text words of pending location 0
+    uint64_t p_tw[W <= RH_KEEP_TW_MAXW ? W : 1]; // aligned text words of pending location 0 (kept for reads of up to 128 bases;
+                                          // longer ones read the text again when they score: the registers are worth more)
     uint32_t p_n, p_nev, p_ev, cslot;     // locations, events, 1 bit per event (= location), slot of the memo
     uint32_t nhit; // matchAll: hits appended for this read
     // work counters
@@ -121,10 +125,10 @@ __device__ __forceinline__ void flush_pending(const MatchArgs &a, LaneState<W, S
         } else {
             revcomp_words<W>(s.O, Ow, s.patl);
         }
-        if (j == 0) {
+        if (j == 0 && W <= RH_KEEP_TW_MAXW) {
 #pragma unroll
-            for (int i = 0; i < W; ++i) tw[i] = s.p_tw[i];
-        } else { // second location of a read: the text is read again
+            for (int i = 0; i < W; ++i) tw[i] = s.p_tw[W <= RH_KEEP_TW_MAXW ? i : 0];
+        } else { // second location of a read (any location of a long read): the text is read again
             const uint64_t wi = pos >> 5;
             const unsigned sh = 2u * (pos & 31);
             uint64_t t[W + 2];
@@ -239,9 +243,9 @@ __device__ __forceinline__ void process_candidate(const MatchArgs &a, LaneState<
             if (s.p_n) { s.p_pos[1] = pos; s.p_meta[1] = meta0; }
             else {
                 s.p_pos[0] = pos; s.p_meta[0] = meta0;
-                if (SCORES) {
+                if (SCORES && W <= RH_KEEP_TW_MAXW) {
 #pragma unroll
-                    for (int j = 0; j < W; ++j) s.p_tw[j] = tw[j];
+                    for (int j = 0; j < W; ++j) s.p_tw[W <= RH_KEEP_TW_MAXW ? j : 0] = tw[j];
                 }
             }
             s.cslot = s.p_n++;
