@@ -55,21 +55,24 @@ def make_reads(sym, n_reads, patl, errprob, seed):
     return b, q
 
 
-def write_fastq(path, b, q):
+def write_fastq(path, b, q, step=2_000_000):
     n, patl = b.shape
     w = 1 + 10 + 1 + patl + 3 + patl + 1
-    rec = np.empty((n, w), dtype=np.uint8)
-    rec[:, 0] = ord("@")
-    i = np.arange(n, dtype=np.int64)
-    for d in range(10):
-        rec[:, 1 + d] = 48 + (i // 10 ** (9 - d)) % 10
-    rec[:, 11] = 10
-    rec[:, 12:12 + patl] = np.frombuffer(b"ACGT", dtype=np.uint8)[b]
-    rec[:, 12 + patl] = 10; rec[:, 13 + patl] = ord("+"); rec[:, 14 + patl] = 10
-    rec[:, 15 + patl:15 + 2 * patl] = q + 33
-    rec[:, 15 + 2 * patl] = 10
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
     with open(path, "wb") as f:
-        f.write(rec.tobytes())
+        for lo in range(0, n, step):                                  # (in slices: a record is 216 bytes)
+            hi = min(n, lo + step)
+            rec = np.empty((hi - lo, w), dtype=np.uint8)
+            rec[:, 0] = ord("@")
+            i = np.arange(lo, hi, dtype=np.int64)
+            for d in range(10):
+                rec[:, 1 + d] = 48 + (i // 10 ** (9 - d)) % 10
+            rec[:, 11] = 10
+            rec[:, 12:12 + patl] = lut[b[lo:hi]]
+            rec[:, 12 + patl] = 10; rec[:, 13 + patl] = ord("+"); rec[:, 14 + patl] = 10
+            rec[:, 15 + patl:15 + 2 * patl] = q[lo:hi] + 33
+            rec[:, 15 + 2 * patl] = 10
+            f.write(rec.tobytes())
 
 
 def main():
@@ -121,7 +124,11 @@ def main():
         m.set_text_symbols(0, sym, frag)
         m.build_index_block()
         og = ora.Genome(sym, frag)
-        signs, poss = zip(*[m.index_export(k) for k in range(6)])
+        signs, poss = [], []
+        for k in range(6):
+            sg, ps = m.index_export(k)
+            signs.append(sg); poss.append(ps)
+            print("  list %d exported" % k, flush=True)
         ix = ora.CompactIndex(og, 32, list(signs), list(poss))
         m.close()
         p = ora.make_params(seedl=32, seedkmax=2, totalkmax=3, scores=True, threads=args.threads)
@@ -131,23 +138,31 @@ def main():
         sel = np.nonzero((st == 1) | (st == 2))[0]
         print("oracle: %d of %d reads uniquely matched, %.0f s" % (sel.shape[0], args.reads, time.time() - t0), flush=True)
         import pandas as pd
-        df = pd.read_csv(out, sep="\t", header=None, dtype=str, keep_default_na=False, quoting=3, engine="c")
-        ok = df.shape == (sel.shape[0], 11)
-        checks = {"lines": bool(ok)}
-        if ok:
-            checks["id"] = bool(np.array_equal(df[0].astype(np.int64).values, sel))
-            inv = st[sel] == 2
-            eb = b[sel]
+        names = ("lines", "id", "sequence", "score", "constant_columns", "strand", "fragment", "position", "errors")
+        checks = {k: True for k in names}
+        lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+        at = 0
+        for df in pd.read_csv(out, sep="\t", header=None, dtype=str, keep_default_na=False, quoting=3, engine="c", chunksize=4_000_000):
+            m_ = df.shape[0]
+            s_ = sel[at:at + m_]
+            if s_.shape[0] != m_ or df.shape[1] != 11:
+                checks["lines"] = False
+                break
+            checks["id"] &= bool(np.array_equal(df[0].astype(np.int64).values, s_))
+            inv = st[s_] == 2
+            eb = b[s_]
             eb[inv] = (3 - eb[inv])[:, ::-1]
-            want_seq = np.frombuffer(b"ACGT", dtype=np.uint8)[eb]
             got_seq = np.array(df[1].values, dtype="S%d" % args.patl).view(np.uint8).reshape(-1, args.patl)
-            checks["sequence"] = bool(np.array_equal(got_seq, want_seq))
-            checks["score"] = bool(np.array_equal(np.array(df[2].values, dtype=str), np.char.mod("%g", score[sel].astype(np.float64))))
-            checks["constant_columns"] = bool((df[3] == "1").all() and (df[4] == "a").all() and (df[5] == str(args.patl)).all() and (df[9] == "").all())
-            checks["strand"] = bool(np.array_equal(df[6].values == "-", inv))
-            checks["fragment"] = bool((df[7] == " random").all())
-            checks["position"] = bool(np.array_equal(df[8].astype(np.int64).values, po[sel] + 1))
-            checks["errors"] = bool(np.array_equal(df[10].astype(np.int64).values, er[sel]))
+            checks["sequence"] &= bool(np.array_equal(got_seq, lut[eb]))
+            checks["score"] &= bool(np.array_equal(np.array(df[2].values, dtype=str), np.char.mod("%g", score[s_].astype(np.float64))))
+            checks["constant_columns"] &= bool((df[3] == "1").all() and (df[4] == "a").all() and (df[5] == str(args.patl)).all() and (df[9] == "").all())
+            checks["strand"] &= bool(np.array_equal(df[6].values == "-", inv))
+            checks["fragment"] &= bool((df[7] == " random").all())
+            checks["position"] &= bool(np.array_equal(df[8].astype(np.int64).values, po[s_] + 1))
+            checks["errors"] &= bool(np.array_equal(df[10].astype(np.int64).values, er[s_]))
+            at += m_
+            print("  compared %d lines" % at, flush=True)
+        checks["lines"] &= at == sel.shape[0]
         res["tsv_equals_oracle"] = bool(all(checks.values()))
         res["checks"] = checks
         print("TSV vs oracle: %s (%.0f s)" % (checks, time.time() - t0), flush=True)
