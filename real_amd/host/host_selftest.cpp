@@ -9,6 +9,7 @@
 #include <fstream>
 #include <iostream>
 
+#include "FastFormat.hpp"
 #include "GenomeText.hpp"
 #include "HostIndex.hpp"
 #include "ReadReader.hpp"
@@ -78,6 +79,35 @@ int main(int argc, char **argv)
             std::ofstream m((d + "/meta.txt").c_str());
             m << B.n << " " << (B.have_next ? 1 : 0) << " " << B.sig_bytes << " " << w.size() << "\n";
             return 0;
+        }
+        if (cmd == "fmtcheck" && argc == 3) { // fastformat::fmt_g6 against printf's %g on argv[2] floats
+            const uint64_t n = strtoull(argv[2], 0, 10);
+            uint64_t bad = 0, s = 0x9E3779B97F4A7C15ull;
+            auto next = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+            auto check = [&](float f) {
+                char a[64], b[64];
+                const int la = fastformat::fmt_g6(f, a), lb = snprintf(b, sizeof b, "%g", (double)f);
+                if (la != lb || memcmp(a, b, (size_t)la)) { if (bad++ < 20) { a[la] = 0; std::cerr << "fmt_g6 " << a << " != " << b << std::endl; } }
+            };
+            for (uint64_t i = 0; i < n; ++i) {
+                const uint64_t r = next();
+                uint32_t u = (uint32_t)r;
+                float f;
+                memcpy(&f, &u, 4);                                       // any bit pattern (nan, inf, denormals: the fallback)
+                check(f);
+                check((float)((double)(int64_t)(r >> 40) / 1000.0 - 8000.0)); // score-like values with a few decimals
+                check((float)(int32_t)(r >> 44));                         // integers
+                const int k = (int)((r >> 32) % 21) - 5;                   // around the powers of ten, from both sides
+                double pw = 1; for (int j = 0; j < (k < 0 ? -k : k); ++j) pw *= 10;
+                const double c = k < 0 ? 1 / pw : pw;
+                float g = (float)c;
+                uint32_t gu; memcpy(&gu, &g, 4);
+                gu += (uint32_t)(r % 7) - 3; memcpy(&g, &gu, 4);
+                check(g); check(-g);
+                check((float)(c * 9.999995)); check((float)(c * 0.9999995)); check((float)(c * 1.2345675)); check((float)(c * 999999.5 / 1e5));
+            }
+            std::cout << bad << std::endl;
+            return bad ? 1 : 0;
         }
         if (cmd == "options") {
             RealOptions o(argc - 1, argv + 1);

@@ -31,6 +31,7 @@
 #include <thread>
 #include <vector>
 
+#include "FastFormat.hpp"
 #include "GenomeText.hpp"
 #include "HostIndex.hpp"
 #include "ReadReader.hpp"
@@ -119,8 +120,8 @@ struct Ranges { std::vector<std::vector<std::string>> names; std::vector<std::ve
 
 // ---- output lines (printMatchUnlocked, matchUniqueImplementation.cpp:252-321) --------------------------
 // id \t sequence as matched \t score|"" \t 1 \t a \t patl \t +|- \t fragment name \t 1-based position \t "" \t errors \n
-// Written straight into the thread's buffer: table lookups for the sequence, hand-rolled decimal numbers; only the score
-// goes through printf's %g (operator<<(float) is %g with six significant digits: the same digits by the same code).
+// Written straight into the thread's buffer: table lookups for the sequence, hand-rolled decimal numbers, and the score by
+// fastformat::fmt_g6 -- the digits of printf's %g, which is what operator<<(float) prints, from integer arithmetic.
 struct SeqTables {
     char fwd[256], rc[256], map_fwd[5], map_rc[5];
     SeqTables()
@@ -152,7 +153,7 @@ inline char *lineRoom(std::string &out, size_t bytes)
 inline char *putTail(char *p, bool scores, float score, uint64_t patl, bool inverted, const std::string &fragname, uint64_t pos1, unsigned errors)
 {
     *p++ = '\t';
-    if (scores) p += snprintf(p, 32, "%g", (double)score);
+    if (scores) p += fastformat::fmt_g6(score, p); // operator<<(float): %g, six significant digits
     memcpy(p, "\t1\ta\t", 5); p += 5;
     p = putUint(p, patl);
     *p++ = '\t'; *p++ = inverted ? '-' : '+'; *p++ = '\t';

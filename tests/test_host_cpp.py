@@ -95,3 +95,10 @@ def test_realoptions_cpp(selftest, tmp_path):
     # missing mandatory argument / missing value: error exit, like the reference's exceptions
     assert subprocess.call([selftest, "options", "-t", "g.fa"], stderr=subprocess.DEVNULL) != 0
     assert subprocess.call([selftest, "options", "-t", "g.fa", "-p", str(fq), "-o"], stderr=subprocess.DEVNULL) != 0
+
+
+def test_fast_score_formatter_equals_printf(selftest):
+    """the score column: fastformat::fmt_g6 (integer arithmetic) against printf's %g -- which is what the reference's
+    operator<<(float) prints -- on random bit patterns, score-like values, integers and both sides of every power of ten"""
+    r = subprocess.run([selftest, "fmtcheck", "400000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "0", r.stderr[-2000:]
