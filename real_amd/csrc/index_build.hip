@@ -478,24 +478,29 @@ static int index_from_sorted(real_hip_ctx *ctx, BuildScratch &S, int list, const
     const uint32_t nb = 1u << pb;
     const bool rows = ctx->fine == 3;
     int rc;
-    // the tables of a previous block / build go first: their bytes are needed
-    rh_release(ctx, ctx->bkt[list]);
-    if (rows || !n) rh_release(ctx, ctx->ent[list]);
+    // The tables of a previous block stay allocated when they have about the size this block needs (the next block of
+    // a genome, the next file of a directory: same layout, and hipMalloc of 200 GB costs seconds); otherwise they go
+    // first, their bytes are needed.
+    auto fit = [&](DevBuf &b, size_t need) -> int {
+        if (b.cap >= need && b.cap <= 2 * need + ((size_t)1 << 20)) return REAL_HIP_OK;
+        rh_release(ctx, b);
+        return rh_reserve(ctx, b, need);
+    };
     if (!n) {
         const size_t esz = rows ? 128 : (ctx->fine ? 16 : 4);
-        if ((rc = rh_reserve(ctx, ctx->bkt[list], ((size_t)nb + 1) * esz))) return rc;
-        if ((rc = rh_reserve(ctx, ctx->ent[list], sizeof(uint2)))) return rc;
+        if ((rc = fit(ctx->bkt[list], ((size_t)nb + 1) * esz))) return rc;
+        if ((rc = fit(ctx->ent[list], sizeof(uint2)))) return rc;
         RH_HIP(ctx, hipMemsetAsync(ctx->bkt[list].p, 0, ((size_t)nb + 1) * esz, ctx->stream));
         return REAL_HIP_OK;
     }
     uint2 *d_ent = S.ent;
     if (!rows) {
-        if ((rc = rh_reserve(ctx, ctx->ent[list], n * sizeof(uint2)))) return rc;
+        if ((rc = fit(ctx->ent[list], n * sizeof(uint2)))) return rc;
         d_ent = (uint2 *)ctx->ent[list].p;
     }
     uint32_t *d_bkt = S.bkt;
     if (!ctx->fine) {
-        if ((rc = rh_reserve(ctx, ctx->bkt[list], ((size_t)nb + 1) * 4))) return rc;
+        if ((rc = fit(ctx->bkt[list], ((size_t)nb + 1) * 4))) return rc;
         d_bkt = (uint32_t *)ctx->bkt[list].p;
     }
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
@@ -518,8 +523,8 @@ static int index_from_sorted(real_hip_ctx *ctx, BuildScratch &S, int list, const
         uint32_t n_ovf = 0;
         RH_HIP(ctx, hipMemcpyAsync(&n_ovf, S.ostart + nb, 4, hipMemcpyDeviceToHost, ctx->stream));
         RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if ((rc = rh_reserve(ctx, ctx->bkt[list], (size_t)nb * 128))) return rc;
-        if ((rc = rh_reserve(ctx, ctx->ent[list], ((size_t)n_ovf + 1) * sizeof(uint2)))) return rc;
+        if ((rc = fit(ctx->bkt[list], (size_t)nb * 128))) return rc;
+        if ((rc = fit(ctx->ent[list], ((size_t)n_ovf + 1) * sizeof(uint2)))) return rc;
         rh_time_begin(ctx, ctx->stream, REAL_HIP_K_INDEX);
         hipLaunchKernelGGL(rows_fill_kernel, dim3((unsigned)(((uint64_t)nb + 255) / 256)), b1, 0, ctx->stream, (const uint32_t *)d_bkt,
                            (const uint2 *)d_ent, (uint64_t)nb, pbits, fbits, (const uint32_t *)S.ostart, (uint4 *)ctx->bkt[list].p, (uint2 *)ctx->ent[list].p);
@@ -528,7 +533,7 @@ static int index_from_sorted(real_hip_ctx *ctx, BuildScratch &S, int list, const
         return REAL_HIP_OK;
     }
     if (ctx->fine) {
-        if ((rc = rh_reserve(ctx, ctx->bkt[list], ((size_t)nb + 1) * sizeof(uint4)))) return rc;
+        if ((rc = fit(ctx->bkt[list], ((size_t)nb + 1) * sizeof(uint4)))) return rc;
         if (ctx->fine == 1)
             hipLaunchKernelGGL(fine_table_kernel, dim3((unsigned)(((uint64_t)nb + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
                                (const uint32_t *)d_bkt, (const uint2 *)d_ent, (uint64_t)nb, pbits, fbits, (uint4 *)ctx->bkt[list].p);
@@ -634,8 +639,6 @@ int rh_index_build_device(real_hip_ctx *ctx, uint64_t first_window, uint64_t max
     const uint32_t *d_wpos = nullptr;
     uint64_t cnt = 0;
     int rc;
-    // the tables of the previous block go first: their bytes are needed
-    for (int k = 0; k < 6; ++k) { rh_release(ctx, ctx->ent[k]); rh_release(ctx, ctx->bkt[k]); }
     if (ctx->n_wild == 0) { // every window from first_window on: the starts are generated, not stored
         cnt = (first_window < nwin_all) ? (nwin_all - first_window) : 0;
         if (cnt > max_entries) cnt = max_entries;

@@ -351,7 +351,6 @@ extern "C" int real_hip_set_index_block(real_hip_ctx *ctx, uint64_t n, const voi
     ctx->have_index = false;
     for (int k = 0; k < 6; ++k)
         if (n && (!sign[k] || !pos[k])) return rh_fail(ctx, REAL_HIP_E_INVALID, "null list", hipSuccess);
-    for (int k = 0; k < 6; ++k) { rh_release(ctx, ctx->ent[k]); rh_release(ctx, ctx->bkt[k]); } // the previous block's tables
     ctx->n_entries = n;
     rh_choose_tables(ctx, n);
     int rc = rh_index_from_host_lists(ctx, n, sign, pos, sb);
@@ -615,23 +614,13 @@ static int pipeline_init(real_hip_ctx *ctx)
     return REAL_HIP_OK;
 }
 
-extern "C" int real_hip_match_unique_submit(real_hip_ctx *ctx, const real_hip_batch *b, uint64_t *info, float *score, uint32_t slot, int fresh)
+// everything of a submit that touches the streams; a failure half way leaves copies of the caller's memory in flight,
+// which the wrapper below drains before it reports the error
+static int submit_unique(real_hip_ctx *ctx, RhSlot &S, int slot, const real_hip_batch &bv, uint64_t *info, float *score, int fresh)
 {
-    RH_ENTER(ctx);
-    if (slot >= REAL_HIP_SLOTS) return rh_fail(ctx, REAL_HIP_E_INVALID, "slot", hipSuccess);
-    RhSlot &S = ctx->slot[slot];
-    if (S.busy) return rh_fail(ctx, REAL_HIP_E_STATE, "slot in flight: real_hip_wait first", hipSuccess);
-    real_hip_batch bv;
-    int rc = batch_view(ctx, b, bv);
-    if (rc) return rc;
-    if (bv.on_device) return rh_fail(ctx, REAL_HIP_E_INVALID, "submit takes host batches (device batches: the synchronous calls)", hipSuccess);
     const uint64_t n = bv.n_reads;
     const bool sc = ctx->prm.scores != 0;
-    if (n && (!info || (sc && !score))) return rh_fail(ctx, REAL_HIP_E_INVALID, "null info/score", hipSuccess);
-    if ((rc = pipeline_init(ctx))) return rc;
-    S.n = n; S.status = REAL_HIP_OK;
-    if (!n) { S.busy = true; S.empty = true; return REAL_HIP_OK; }
-    S.empty = false;
+    int rc;
     // records: uploaded (they are in/out: folds compose across genome blocks), or initialised on the device (fresh:
     // uniqueinfo(numpat), matchUniqueImplementation.cpp:1094-1097 -- NoMatch, score -FLT_MAX)
     if ((rc = rh_reserve(ctx, S.info, n * 8))) return rc;
@@ -648,15 +637,39 @@ extern "C" int real_hip_match_unique_submit(real_hip_ctx *ctx, const real_hip_ba
     MatchArgs a;
     fill_args(ctx, s, n, a);
     a.info = (uint64_t *)S.info.p; a.score = (float *)S.score.p;
-    ctx->time_slot = (int)slot;
-    rc = rh_launch_match(ctx, a, false, (int)slot);
-    ctx->time_slot = -1;
-    if (rc) return rc;
+    if ((rc = rh_launch_match(ctx, a, false, slot))) return rc;
     RH_HIP(ctx, hipEventRecord(S.matched, ctx->stream));
     RH_HIP(ctx, hipStreamWaitEvent(ctx->down_stream, S.matched, 0));
     RH_HIP(ctx, hipMemcpyAsync(info, S.info.p, n * 8, hipMemcpyDeviceToHost, ctx->down_stream));
     if (sc) RH_HIP(ctx, hipMemcpyAsync(score, S.score.p, n * 4, hipMemcpyDeviceToHost, ctx->down_stream));
     RH_HIP(ctx, hipEventRecord(S.done, ctx->down_stream));
+    return REAL_HIP_OK;
+}
+
+extern "C" int real_hip_match_unique_submit(real_hip_ctx *ctx, const real_hip_batch *b, uint64_t *info, float *score, uint32_t slot, int fresh)
+{
+    RH_ENTER(ctx);
+    if (slot >= REAL_HIP_SLOTS) return rh_fail(ctx, REAL_HIP_E_INVALID, "slot", hipSuccess);
+    RhSlot &S = ctx->slot[slot];
+    if (S.busy) return rh_fail(ctx, REAL_HIP_E_STATE, "slot in flight: real_hip_wait first", hipSuccess);
+    real_hip_batch bv;
+    int rc = batch_view(ctx, b, bv);
+    if (rc) return rc;
+    if (bv.on_device) return rh_fail(ctx, REAL_HIP_E_INVALID, "submit takes host batches (device batches: the synchronous calls)", hipSuccess);
+    const uint64_t n = bv.n_reads;
+    if (n && (!info || (ctx->prm.scores && !score))) return rh_fail(ctx, REAL_HIP_E_INVALID, "null info/score", hipSuccess);
+    if ((rc = pipeline_init(ctx))) return rc;
+    S.n = n; S.status = REAL_HIP_OK;
+    if (!n) { S.busy = true; S.empty = true; return REAL_HIP_OK; }
+    S.empty = false;
+    if ((rc = submit_unique(ctx, S, (int)slot, bv, info, score, fresh))) {
+        // nothing of the caller's memory may stay in flight behind an error
+        const std::string msg = ctx->last_error;
+        (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->down_stream);
+        (void)hipGetLastError();
+        ctx->last_error = msg;
+        return rc;
+    }
     S.busy = true;
     return REAL_HIP_OK;
 }

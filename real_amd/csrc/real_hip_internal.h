@@ -153,7 +153,6 @@ struct real_hip_ctx {
     DevBuf s_bases, s_qual, s_off, s_info, s_score, s_nflags;
     RhSlot slot[REAL_HIP_SLOTS];                    // submit / wait
     hipStream_t copy_stream = nullptr, down_stream = nullptr;
-    int time_slot = -1;
     DevBuf maxpatl, ovf_list, ovf_count;
     unsigned long long *h_state = nullptr; // pinned: {reads handed over, error flags} of the last launch of slot 0, slot 1, the synchronous calls
     // read ingestion (read_parse.hip)

@@ -44,7 +44,9 @@ void GenomeText::load(const std::string &fasta)
         if (map != MAP_FAILED) { data = (const char *)map; (void)madvise(map, size, MADV_SEQUENTIAL); }
     }
     size_t n = size;
+    bool fd_open = true;
     if (!data) {
+        fd_open = false; // (the stream owns the descriptor from here)
         FILE *f = fdopen(fd, "rb");
         if (!f) { close(fd); throw std::runtime_error("Could not open text file " + fasta); }
         char buf[1 << 16];
@@ -114,7 +116,7 @@ void GenomeText::load(const std::string &fasta)
         }
     }
     if (map != MAP_FAILED) munmap(map, size);
-    if (slurp.empty()) close(fd);
+    if (fd_open) close(fd);
     if (frag_start.empty()) throw std::runtime_error("no FASTA record in " + fasta);
     frag_start.push_back(sym.size()); // "terminal"
     // empty records cannot be represented by the reference's RangeVector either (fillRange)
