@@ -195,24 +195,28 @@ inline Record unpack(uint64_t rec)
 
 // The lines of reads [0, n) of one block, formatted by all host threads (each a contiguous range of reads into its
 // own buffer) and written in read order with one large write per buffer.  line(i, out) appends read i's line(s).
+struct alignas(128) LineBuf { std::string s; }; // (a cache line pair of its own: the threads update their string's length line by line)
+
 template <class LineFn>
 void formatAndWrite(uint64_t n, FILE *out, Timers &T, LineFn line)
 {
     const int nt = std::max(1, omp_get_max_threads());
-    static std::vector<std::string> buf; // (kept across calls: the pages of a buffer are touched once, not once per block)
-    if ((int)buf.size() < nt) buf.resize((size_t)nt);
+    static std::vector<LineBuf> buf; // (kept across calls: the pages of a buffer are touched once, not once per block)
+    if ((int)buf.size() < nt) buf = std::vector<LineBuf>((size_t)nt);
     const double t0 = now_s();
 #pragma omp parallel num_threads(nt)
     {
         const int t = omp_get_thread_num();
         const uint64_t lo = n * (uint64_t)t / nt, hi = n * (uint64_t)(t + 1) / nt;
-        std::string &b = buf[(size_t)t];
+        std::string b;
+        b.swap(buf[(size_t)t].s); // (worked on as a local: its length and pointer live in registers / this thread's stack)
         b.clear();
         for (uint64_t i = lo; i < hi; ++i) line(i, b);
+        b.swap(buf[(size_t)t].s);
     }
     const double t1 = now_s();
     for (int t = 0; t < nt; ++t) {
-        const std::string &b = buf[(size_t)t];
+        const std::string &b = buf[(size_t)t].s;
         if (!b.empty() && fwrite(b.data(), 1, b.size(), out) != b.size()) throw std::runtime_error("write to the output file failed");
         T.out_bytes += b.size();
     }
@@ -538,7 +542,6 @@ int matchUnique(const RealOptions &o)
                 T.parse += now_s() - td;
                 const char *text = ch[g].text;
                 const uint64_t base = first_id[g];
-                std::vector<uint64_t> cnt((size_t)omp_get_max_threads() + 1, 0);
                 formatAndWrite(n, out, T, [&](uint64_t i, std::string &b) {
                     const Record r = unpack(info[base + i]);
                     if (r.st != 1 && r.st != 2) return; // NoMatch / NonUnique / Gapped print nothing
@@ -549,28 +552,27 @@ int matchUnique(const RealOptions &o)
                     const uint64_t patl = off[i + 1] - off[i];
                     appendLine(b, text + id_start[i], il, text + id_start[i] + il + 1, nullptr, patl, o.scores, o.scores ? score[base + i] : 0.f, r.st == 2,
                                RS.names[r.file][r.frag], r.pos - RS.starts[r.file][r.frag] + 1, r.errors);
-                    cnt[(size_t)omp_get_thread_num()]++;
                 });
-                for (uint64_t c : cnt) unique += c;
             }
         },
         [&](std::vector<ReadBlock> &blk, size_t used) {
             for (size_t g = 0; g < used; ++g) {
                 const ReadBlock &b = blk[g];
-                std::vector<uint64_t> cnt((size_t)omp_get_max_threads() + 1, 0);
                 formatAndWrite(b.size(), out, T, [&](uint64_t i, std::string &s) {
                     const Record r = unpack(info[b.first_id + i]);
                     if (r.st != 1 && r.st != 2) return;
                     const uint64_t lo = b.offsets[i], patl = b.offsets[i + 1] - lo;
                     appendLine(s, b.ids[i].data(), b.ids[i].size(), nullptr, &b.bases[lo], patl, o.scores, o.scores ? score[b.first_id + i] : 0.f, r.st == 2,
                                RS.names[r.file][r.frag], r.pos - RS.starts[r.file][r.frag] + 1, r.errors);
-                    cnt[(size_t)omp_get_thread_num()]++;
                 });
-                for (uint64_t c : cnt) unique += c;
             }
         });
     if (fflush(out) != 0) throw std::runtime_error("write to the output file failed");
     if (out != stdout) fclose(out);
+    // (counted here, once, and not line by line inside the formatter: sixteen threads bumping neighbouring counters
+    // cost more than formatting the lines)
+#pragma omp parallel for reduction(+ : unique) schedule(static)
+    for (uint64_t i = 0; i < numpat; ++i) { const unsigned st = (unsigned)(info[i] >> 61); unique += (st == 1 || st == 2); }
     std::cerr << "unique: " << unique << std::endl; // :1488
     T.reads = numpat; T.lines = unique; T.total = now_s() - t_begin;
     T.print();
