@@ -16,7 +16,9 @@
 //
 // Deliberate differences from reference quirks (SURVEY 8a "quirks"): matchAll handles FASTQ input
 // (quirk 1) and writes every line (quirk 2); the exit status is non-zero on errors (quirk 6).
+#include <fcntl.h>
 #include <omp.h>
+#include <unistd.h>
 
 #include <cfloat>
 #include <chrono>
@@ -282,8 +284,8 @@ class RawChunker {
 public:
     RawChunker(const std::string &fn, bool fastq, size_t chunk_bytes, size_t n_buffers) : lpr_(fastq ? 4 : 2)
     {
-        f_ = fopen(fn.c_str(), "rb");
-        if (!f_) throw std::runtime_error("Unable to open pattern file.");
+        fd_ = open(fn.c_str(), O_RDONLY);
+        if (fd_ < 0) throw std::runtime_error("Unable to open pattern file.");
         for (size_t i = 0; i < n_buffers; ++i) {
             Chunk c;
             c.text = (char *)real_hip_host_alloc(chunk_bytes);
@@ -298,7 +300,7 @@ public:
     {
         if (next_.valid()) next_.wait();
         for (auto &c : pool_) real_hip_host_free(c.text);
-        if (f_) fclose(f_);
+        if (fd_ >= 0) close(fd_);
     }
     // the next chunk (the caller's until it hands it back with release); false at the end of the file
     bool next(Chunk &out, double &wait_s)
@@ -329,6 +331,8 @@ private:
         free_.pop_back();
         next_ = std::async(std::launch::async, [this, id]() { return fill(id) ? id : -1; });
     }
+    // reads the next chunk with kReaders threads (pread of a slice each, then the newlines of the slice are counted
+    // while it is hot), cuts it behind the last newline whose index is a multiple of the lines per record
     bool fill(int id)
     {
         Chunk &c = pool_[(size_t)id];
@@ -337,22 +341,59 @@ private:
         if (have) memcpy(c.text, carry_.data(), have);
         c.file_offset = offset_;
         carry_.clear();
-        const size_t got = eof_ ? 0 : fread(c.text + have, 1, c.cap - have, f_);
-        if (have + got < c.cap) eof_ = true;
+        const size_t want = eof_ ? 0 : c.cap - have;
+        constexpr int kReaders = 4;
+        size_t got_s[kReaders] = {0, 0, 0, 0}, nl_s[kReaders] = {0, 0, 0, 0};
+        bool err = false;
+        auto slice = [&](int k) {
+            const size_t lo = want * (size_t)k / kReaders, hi = want * (size_t)(k + 1) / kReaders;
+            size_t done = 0;
+            while (lo + done < hi) {
+                const ssize_t r = pread(fd_, c.text + have + lo + done, hi - lo - done, (off_t)(fpos_ + lo + done));
+                if (r < 0) { err = true; break; }
+                if (r == 0) break; // end of file
+                done += (size_t)r;
+            }
+            got_s[k] = done;
+            size_t nl = 0;
+            const char *b = c.text + have + lo, *e = b + done;
+            if (k == 0) b = c.text; // (the carry belongs to the first slice)
+            for (const char *q = b; (q = (const char *)memchr(q, '\n', (size_t)(e - q))); ++q) nl++;
+            nl_s[k] = nl;
+        };
+        if (want) {
+            std::thread th[kReaders - 1];
+            for (int k = 1; k < kReaders; ++k) th[k - 1] = std::thread(slice, k);
+            slice(0);
+            for (auto &t : th) t.join();
+        } else {
+            slice(0); // (nothing to read: the newlines of the carry)
+        }
+        if (err) throw std::runtime_error("reading the pattern file failed");
+        size_t got = 0, lines = 0;
+        for (int k = 0; k < kReaders; ++k) { got += got_s[k]; lines += nl_s[k]; } // (a short slice = the end of the file: the slices behind it are empty)
+        fpos_ += got;
+        if (got < want || !want) eof_ = true;
         c.size = have + got;
         if (!c.size) return false;
         if (!eof_) {
-            size_t lines = 0, cut = 0;
-            for (const char *p = c.text, *e = p + c.size; (p = (const char *)memchr(p, '\n', (size_t)(e - p))); ++p)
-                if (++lines % lpr_ == 0) cut = (size_t)(p - c.text) + 1;
-            if (!cut) throw std::runtime_error("a read record longer than the text chunk");
+            // behind newline number lines - lines % lpr: walk back over the lines % lpr newlines of the incomplete record
+            size_t back = lines % lpr_, cut = c.size;
+            const char *q = c.text + c.size;
+            for (size_t k = 0; k <= back; ++k) {
+                q = (const char *)memrchr(c.text, '\n', (size_t)(q - c.text));
+                if (!q) { cut = 0; break; }
+                cut = (size_t)(q - c.text) + 1;
+            }
+            if (lines < lpr_ || !cut) throw std::runtime_error("a read record longer than the text chunk");
             carry_.assign(c.text + cut, c.text + c.size);
             c.size = cut;
         }
         offset_ += c.size;
         return true;
     }
-    FILE *f_ = nullptr;
+    int fd_ = -1;
+    uint64_t fpos_ = 0; // file position behind the bytes read so far
     size_t lpr_;
     bool eof_ = false, done_ = false;
     uint64_t offset_ = 0;
