@@ -92,7 +92,7 @@ void GenomeText::load(const std::string &fasta)
         total += pc[(size_t)t].kept;
         n_wild += pc[(size_t)t].wild;
     }
-    sym.resize(total);
+    sym.resize_uninitialized(total);
     uint8_t *out = sym.data();
 #pragma omp parallel for schedule(static, 1) num_threads(nt)
     for (int t = 0; t < nt; ++t) {

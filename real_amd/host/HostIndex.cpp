@@ -5,7 +5,7 @@
 #include <algorithm>
 #include <cstring>
 
-void enumerateWindows(const std::vector<uint8_t> &sym, unsigned l, std::vector<uint32_t> &wpos)
+void enumerateWindows(const SymArray &sym, unsigned l, std::vector<uint32_t> &wpos)
 {
     wpos.clear();
     uint64_t run = 0;
@@ -53,7 +53,7 @@ static void radix_sort_pairs(std::vector<K> &key, std::vector<uint32_t> &val, un
     if (ka != key.data()) { memcpy(key.data(), ka, n * sizeof(K)); memcpy(val.data(), va, n * 4); }
 }
 
-void buildHostIndexBlock(const std::vector<uint8_t> &sym, const std::vector<uint32_t> &wpos, unsigned l, uint64_t first,
+void buildHostIndexBlock(const SymArray &sym, const std::vector<uint32_t> &wpos, unsigned l, uint64_t first,
                          uint64_t max_entries, int threads, HostIndexBlock &out)
 {
     const uint64_t total = wpos.size();
@@ -65,7 +65,7 @@ void buildHostIndexBlock(const std::vector<uint8_t> &sym, const std::vector<uint
     for (int j = 0; j < 4; ++j) m[j].resize(n);
 #pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(static)
     for (int64_t i = 0; i < (int64_t)n; ++i) {
-        const uint8_t *s = &sym[wpos[first + i]];
+        const uint8_t *s = sym.data() + wpos[first + i];
         for (int j = 0; j < 4; ++j) {
             uint64_t v = 0;
             for (unsigned t = 0; t < q; ++t) v = (v << 2) | (s[j * q + t] & 3);

@@ -7,6 +7,8 @@
 #include <stdint.h>
 #include <vector>
 
+#include "GenomeText.hpp"
+
 struct HostIndexBlock {
     unsigned sig_bytes = 4;              // 4 if seedl <= 32 else 8 (real.cpp:219-229)
     uint64_t n = 0;
@@ -18,7 +20,7 @@ struct HostIndexBlock {
 };
 
 // N-free window starts in text order (all blocks); O(n)
-void enumerateWindows(const std::vector<uint8_t> &sym, unsigned seedl, std::vector<uint32_t> &wpos);
+void enumerateWindows(const SymArray &sym, unsigned seedl, std::vector<uint32_t> &wpos);
 // block = windows [first, first+max_entries) of wpos
-void buildHostIndexBlock(const std::vector<uint8_t> &sym, const std::vector<uint32_t> &wpos, unsigned seedl,
+void buildHostIndexBlock(const SymArray &sym, const std::vector<uint32_t> &wpos, unsigned seedl,
                          uint64_t first, uint64_t max_entries, int threads, HostIndexBlock &out);
