@@ -1,9 +1,13 @@
 #!/usr/bin/env python3
-"""Can two RCCL ranks share the one GPU of this box?  (NCCL refuses "duplicate GPUs" by default; if RCCL here does not,
-the N = 2 gathers -- torch.distributed's and the C ABI's own -- get a real RCCL run.)  Started by itself under
-torch.distributed.run with two ranks, both on cuda:0.
+"""The N = 2 gathers of the path -- torch.distributed's (real_amd/distributed.py) and the C ABI's own
+(real_hip_comm_*, real_hip_gather_records / _hits) -- over real RCCL, two ranks started by the script itself.
 
-    python bench_support/rccl_two_ranks_one_gpu.py
+    python bench_support/rccl_two_ranks.py
+
+On a box with two or more GPUs rank r uses GPU r.  On the one-GPU development box both ranks land on cuda:0 and RCCL
+refuses the communicator ("Duplicate GPU detected : rank 0 and rank 1 both on CUDA device ...", tried in round 2): there
+RCCL can only be run with one rank (tests/test_gpu_pipeline.py::test_c_abi_rccl_gather_single_rank), the two-rank logic
+over gloo (tests/test_distributed_cpu.py), and N > 1 over RCCL is left to the driver's multi-GPU run of bench.py.
 """
 import os
 import socket
@@ -24,8 +28,9 @@ def main():
     import torch
     import torch.distributed as dist
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    torch.cuda.set_device(0)
-    dev = torch.device("cuda", 0)
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
     dist.init_process_group("nccl")
     t = torch.ones(1, device=dev) * (rank + 1)
     dist.all_reduce(t)
@@ -48,7 +53,7 @@ def main():
     print("rank %d: torch.distributed gathers ok" % rank, flush=True)
     # the C ABI's own communicator: the id travels through torch's store
     from real_amd.matcher import HipMatcher, RealOptions
-    m = HipMatcher(RealOptions(seedl=32, seedkmax=2, totalkmax=3, scores=True).normalise(), device=0)
+    m = HipMatcher(RealOptions(seedl=32, seedkmax=2, totalkmax=3, scores=True).normalise(), device=local)
     ids = [HipMatcher.comm_id() if rank == 0 else None]
     dist.broadcast_object_list(ids, src=0)
     m.comm_init(ids[0], rank, world)
