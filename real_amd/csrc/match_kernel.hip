@@ -847,17 +847,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
     const uint32_t GL = a.b.gl; // reads the wave stages at a time: GL * max_patl fits its LDS region
     const uint32_t stg_cap = stg_bytes(W, TK) - STG_PAD - 32u; // bytes of a group the region holds (skew, pad, over-read)
     // ---- bases: global -> LDS -> registers
-    bool elig = false, toolong = false;
+    // A read longer than the registers of this instance hold (32 W bases: longer than REAL_HIP_MAX_PATL, or than the
+    // bound the caller declared), and every read of a group whose bytes do not fit the wave's LDS region because of such
+    // a neighbour, is not staged at all: it is given to the wave-per-read matcher, which reads it from LDS words and
+    // checks its eligibility itself.  Only offsets that run backwards or a read beyond REAL_HIP_MAX_PATL_LONG are errors.
+    bool elig = false, toolong = false, give = false;
     for (uint32_t g = 0; g < 64; g += GL) {
         const uint64_t gb = __shfl(o0, (int)g), ge = __shfl(o1, (int)(g + GL - 1));
-        // (offsets that are not monotone, or reads longer than the declared bound: nothing is staged past the region)
         const bool fits = ge >= gb && ge - gb <= stg_cap;
         wave_lds_sync();
         uint32_t l0 = 0;
         if (fits) l0 = stage_wave(stg, a.b.bases + (gb >> bsh), a.b.packed ? ((ge + 3) >> 2) - (gb >> 2) : ge - gb, lane);
         wave_lds_sync();
         const bool in_group = lane >= g && lane < g + GL && r < n;
-        if (in_group && (!fits || o1 < o0 || patl > 32u * W)) toolong = true;
+        if (in_group && (o1 < o0 || patl > REAL_HIP_MAX_PATL_LONG)) toolong = true;
+        else if (in_group && (!fits || patl > 32u * W)) give = patl >= a.l;
         if (in_group && fits && o1 >= o0 && patl >= a.l && patl <= 32u * W) { // matchUniqueImplementation.cpp:376-394
             if (a.b.packed) {
                 pack_read_packed<W>(LdsRow{stg, l0 + (uint32_t)((o0 >> 2) - (gb >> 2))}, patl, (uint32_t)o0 & 3u, s.O);
@@ -867,7 +871,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
             }
         }
     }
-    if (toolong) atomicOr(a.err_flags, 1u); // the host turns this into REAL_HIP_E_INVALID / E_UNSUPPORTED
+    if (toolong) atomicOr(a.err_flags, 1u); // the host turns this into REAL_HIP_E_INVALID
     wave_lds_sync();
     // ---- match
     s.r = r; s.patl = patl; s.p_n = 0; s.nhit = 0;
@@ -879,7 +883,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
         match_read_rows<W, SCORES, ALL, DEFER, TK == 4>(a, s, sLL, stg, elig);
     else if (elig)
         match_read<W, SCORES, ALL, FINE, DEFER>(a, s, sLL, q_pos, q_la);
-    const bool ovf = elig && s.p_n == PEND_OVF;
+    const bool ovf = give || (elig && s.p_n == PEND_OVF);
     if (ovf) {
         // nothing of this read has been delivered: the wave-cooperative matcher does it all and counts it
         const unsigned long long slot = wave_append_slot(a.ovf_count);

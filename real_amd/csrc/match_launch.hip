@@ -22,7 +22,7 @@ int rh_launch_match(real_hip_ctx *ctx, const MatchArgs &args, bool all, int stat
     if (a.b.W < 1 || a.b.W > RH_MAXW) return rh_fail(ctx, REAL_HIP_E_UNSUPPORTED, "read longer than REAL_HIP_MAX_PATL", hipSuccess);
     int rc;
     { // reads a wave stages at a time: their bytes (+ alignment skew, pad, one dword of over-read) fit its LDS region
-        const uint32_t maxlen = a.b.off ? 32u * a.b.W : a.b.upatl;
+        const uint32_t maxlen = (a.b.off || a.b.upatl > 32u * a.b.W) ? 32u * a.b.W : a.b.upatl;
         const uint32_t region = stage[a.b.W - 1](a.ix.fine == 3 ? 3 : (a.ix.fine ? 1 : 0));
         uint32_t gl = 64;
         while (gl > 1 && (uint64_t)gl * maxlen + 16 + 32 > region) gl >>= 1;
@@ -53,6 +53,6 @@ int rh_match_finish(real_hip_ctx *ctx, int state_slot)
     const unsigned long long flags = ctx->h_state[2 * state_slot + 1];
     ctx->h_state[2 * state_slot + 1] = 0;
     if (flags & 1u)
-        return rh_fail(ctx, REAL_HIP_E_INVALID, "a read of the batch is longer than the declared max_patl (or REAL_HIP_MAX_PATL), or the device offsets are not monotone", hipSuccess);
+        return rh_fail(ctx, REAL_HIP_E_INVALID, "a read of the batch is longer than REAL_HIP_MAX_PATL_LONG, or the device offsets are not monotone", hipSuccess);
     return REAL_HIP_OK;
 }

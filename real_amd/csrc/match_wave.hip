@@ -120,11 +120,83 @@ __device__ __forceinline__ WaveRange wave_lookup(const MatchArgs &a, uint64_t sh
     return R;
 }
 
+// ---- reads longer than the registers hold (REAL_HIP_MAX_PATL < patl <= REAL_HIP_MAX_PATL_LONG) -----------------------
+// The read sits in the wave's LDS as words of 32 bases, straight and reverse-complemented; every lane walks the words of
+// its own candidate in run-time loops (an LDS word is the same address in all lanes: a broadcast).
+#define WV_NWL (REAL_HIP_MAX_PATL_LONG / 32u)
+
+// word j of the read (32 bases, MSB first) from the batch; *bad is set if a base is > 3 (byte input)
+__device__ __forceinline__ uint64_t long_word(const MatchArgs &a, uint64_t o0, uint32_t patl, uint32_t j, bool *bad)
+{
+    const uint32_t nb = min(32u, patl - 32u * j);
+    uint64_t w = 0;
+    if (a.b.packed) {
+        const uint64_t g0 = o0 + 32ull * j;          // first base of the word inside the batch
+        const uint8_t *p = a.b.bases + (g0 >> 2);
+        const uint32_t sh = 2u * (uint32_t)(g0 & 3);
+        const uint32_t nbytes = (uint32_t)(((g0 & 3) + nb + 3) >> 2);
+        for (uint32_t k = 0; k < 8 && k < nbytes; ++k) w |= (uint64_t)p[k] << (56 - 8 * k);
+        if (sh) { w <<= sh; if (nbytes > 8) w |= (uint64_t)p[8] >> (8 - sh); }
+    } else {
+        const uint8_t *p = a.b.bases + o0 + 32ull * j;
+        for (uint32_t i = 0; i < nb; ++i) { const uint32_t c = p[i]; if (c > 3) *bad = true; w |= (uint64_t)(c & 3) << (62 - 2 * i); }
+    }
+    if (nb < 32) w &= ~0ull << (64 - 2 * nb);
+    return w;
+}
+
+// Hamming distance of the oriented read (LDS words cur[0..nw)) against text[pos, pos+patl); stops counting once it
+// exceeds limit.  = seedk + RestMatch::computeDistance (RestMatch.hpp:39-81)
+__device__ __forceinline__ uint32_t long_distance(const uint64_t *__restrict__ T, const uint64_t *cur, uint32_t pos, uint32_t nw, uint64_t lastmask,
+                                                  uint32_t limit)
+{
+    const uint64_t wi = pos >> 5;
+    const unsigned sh = 2u * (pos & 31);
+    uint32_t total = 0;
+    uint64_t t0 = T[wi];
+    for (uint32_t j = 0; j < nw && total <= limit; ++j) {
+        const uint64_t t1 = T[wi + j + 1];
+        const uint64_t al = sh ? ((t0 << sh) | (t1 >> (64 - sh))) : t0;
+        const uint64_t x = al ^ cur[j];
+        uint64_t d = ((x >> 1) | x) & M55;
+        if (j + 1 == nw) d &= lastmask;
+        total += __popcll(d);
+        t0 = t1;
+    }
+    return total;
+}
+
+// ComputeScore<...,true>::computeScore (ComputeScore.hpp:50-190) for a long read: the same sequential FP64 sum in base order
+__device__ __forceinline__ float long_score(const double *sLL, const uint64_t *__restrict__ T, const uint64_t *cur, uint32_t pos, uint32_t patl,
+                                            const uint8_t *qual, uint32_t inv)
+{
+    const uint64_t wi = pos >> 5;
+    const unsigned sh = 2u * (pos & 31);
+    const uint32_t nw = (patl + 31) >> 5;
+    double raw = 1.0;
+    uint64_t t0 = T[wi];
+    for (uint32_t j = 0; j < nw; ++j) {
+        const uint64_t t1 = T[wi + j + 1];
+        const uint64_t al = sh ? ((t0 << sh) | (t1 >> (64 - sh))) : t0;
+        const uint64_t rw = cur[j];
+        const uint32_t nb = min(32u, patl - 32u * j);
+        for (uint32_t u = 0; u < nb; ++u) {
+            const uint32_t i = 32u * j + u;
+            const uint32_t ref = (uint32_t)(al >> (62 - 2 * u)) & 3u, rb = (uint32_t)(rw >> (62 - 2 * u)) & 3u;
+            const uint32_t q = qual ? (uint32_t)qual[inv ? patl - 1 - i : i] : 30u; // no qualities => 30 (Pattern.hpp:42-45)
+            raw += sLL[((ref << 8) | (rb << 6) | q) & 1023];
+        }
+        t0 = t1;
+    }
+    return (float)raw;
+}
+
 template <bool SCORES, bool ALL>
 __global__ __launch_bounds__(256) void match_wave_kernel(MatchArgs a)
 {
     constexpr int W = WV_W;
     __shared__ double sLL[SCORES ? RH_LL_SLOTS : 1];
+    __shared__ uint64_t sLong[4][2][WV_NWL]; // per wave: the words of a long read, straight and reverse-complemented
     if (SCORES) {
         for (int i = threadIdx.x; i < 1024; i += 256) sLL[i] = a.LL[i];
         if (threadIdx.x == 0) sLL[RH_LL_ZERO] = 0.0;
@@ -143,10 +215,38 @@ __global__ __launch_bounds__(256) void match_wave_kernel(MatchArgs a)
         const uint64_t o0 = a.b.off ? a.b.off[r] : r * (uint64_t)a.b.upatl;
         const uint32_t patl = a.b.off ? (uint32_t)(a.b.off[r + 1] - o0) : a.b.upatl;
         uint64_t O[W];
-        // (eligible: the matcher handed it over); the same in every lane
-        if (a.b.packed) pack_read_packed<W>(GlobalRow{a.b.bases + (o0 >> 2)}, patl, (uint32_t)o0 & 3u, O);
-        else pack_read<W>(GlobalRow{a.b.bases + o0}, patl, O);
+        const bool lng = patl > 32u * W; // (wave-uniform) the read lives in LDS words instead of O[]
+        uint64_t *const sO = sLong[threadIdx.x >> 6][0], *const sR = sLong[threadIdx.x >> 6][1];
         const uint32_t nw = (patl + 31) >> 5;
+        // The matcher hands over reads it has packed (eligible) and reads it could not even stage (too long for its
+        // registers, or next to such a read): eligibility (matchUniqueImplementation.cpp:376-394) is settled here.
+        bool elig = patl >= l && patl <= REAL_HIP_MAX_PATL_LONG;
+        if (elig && a.b.packed && a.b.nflags && ((a.b.nflags[r >> 3] >> (r & 7)) & 1)) elig = false;
+        if (elig && !lng) {
+            if (a.b.packed) pack_read_packed<W>(GlobalRow{a.b.bases + (o0 >> 2)}, patl, (uint32_t)o0 & 3u, O);
+            else elig = pack_read<W>(GlobalRow{a.b.bases + o0}, patl, O); // (the same in every lane)
+        } else if (elig) {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // (the previous read's words are no longer in use)
+            __builtin_amdgcn_wave_barrier();
+            bool bad = false;
+            for (uint32_t j = lane; j < nw; j += 64) sO[j] = long_word(a, o0, patl, j, &bad);
+            elig = !__any(bad);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // revcomp: out[j] = complement of the 2-bit reversal of the words nw-1-j and nw-2-j, shifted by the pad
+            const uint32_t pad = 64 * nw - 2 * patl;
+            for (uint32_t j = lane; j < nw; j += 64) {
+                const uint64_t x = rev2(sO[nw - 1 - j]), y = (j + 2 <= nw) ? rev2(sO[nw - 2 - j]) : 0ull;
+                const uint64_t v = pad ? ((x << pad) | (y >> (64 - pad))) : x;
+                sR[j] = ~v & ((j + 1 < nw) ? ~0ull : (~0ull << pad));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < W; ++j) O[j] = j < 2 ? sO[(uint32_t)j < nw ? j : 0] : 0ull; // (the seed halves come from the first two words)
+            if (nw < 2) O[1] = 0;
+        }
+        if (!elig) continue; // skipped like the reference skips it; the matcher has written its hit count 0
         const uint64_t lastmask = ~0ull << (64 - 2 * (patl - 32 * (nw - 1)));
         const float eps = (float)(a.filter_mult * (double)patl); // RealOptions.hpp:74-77
         uint64_t info = 0;
@@ -161,12 +261,15 @@ __global__ __launch_bounds__(256) void match_wave_kernel(MatchArgs a)
         if (lane == 0) cR++;
         for (int inv = 0; inv < 2; ++inv) {
             if (inv) { // transposed pattern, Pattern.hpp:105-128
-                uint64_t Rv[W];
-                revcomp_words<W>(O, Rv, patl);
+                if (!lng) {
+                    uint64_t Rv[W];
+                    revcomp_words<W>(O, Rv, patl);
 #pragma unroll
-                for (int j = 0; j < W; ++j) O[j] = Rv[j];
+                    for (int j = 0; j < W; ++j) O[j] = Rv[j];
+                }
                 shi = rhi; slo = rlo;
             }
+            const uint64_t *const cur = inv ? sR : sO; // (long reads)
             const uint32_t so = inv ? (patl - l) : 0u; // RestMatch::getMatchOffset, RestMatch.hpp:84-89
 #pragma unroll 1
             for (int la = 0; la < 6; ++la) {
@@ -233,7 +336,15 @@ __global__ __launch_bounds__(256) void match_wave_kernel(MatchArgs a)
                             cV++;
                             ok = frag_valid(a.t, pos, patl, frag) && !(a.t.has_wild && !wild_free(a.t.wild, pos, patl));
                         }
-                        if (ok) {
+                        if (ok && lng) {
+                            total = long_distance(T, cur, pos, nw, lastmask, a.totalkmax);
+                            if (total <= a.totalkmax) {
+                                hit = true;
+                                cH++; // one updater::update call per list, match.hpp:411
+                                if (SCORES) sc = long_score(sLL, T, cur, pos, patl, a.b.qual ? a.b.qual + o0 : nullptr, (uint32_t)inv);
+                                first = (z0 && z1) ? 0u : (z0 && z2) ? 1u : (z0 && z3) ? 2u : (z1 && z2) ? 3u : (z1 && z3) ? 4u : 5u;
+                            }
+                        } else if (ok) {
                             // Hamming distance of the whole oriented read against text[pos, pos+patl)
                             // = seedk + RestMatch::computeDistance (RestMatch.hpp:39-81)
                             const uint64_t wi = pos >> 5;

@@ -494,9 +494,10 @@ static int stage_batch(real_hip_ctx *ctx, const real_hip_batch &b, Staged &s, co
         s.upatl = b.patl; s.maxpatl = b.patl;
         total = n * (uint64_t)b.patl;
     }
-    // Reads longer than the register budget cannot be matched; the reference has no such
-    // limit (RestWordBuffer grows), so this is an explicit, loud error and not a skip.
-    if (s.maxpatl > REAL_HIP_MAX_PATL) return rh_fail(ctx, REAL_HIP_E_UNSUPPORTED, "read longer than REAL_HIP_MAX_PATL", hipSuccess);
+    // Reads longer than the register budget of the lane-per-read kernels are matched by a wave each (match_wave.hip, from
+    // LDS); beyond REAL_HIP_MAX_PATL_LONG nothing can: the reference has no such limit (RestWordBuffer grows), so that is
+    // an explicit, loud error and not a skip.
+    if (s.maxpatl > REAL_HIP_MAX_PATL_LONG) return rh_fail(ctx, REAL_HIP_E_UNSUPPORTED, "read longer than REAL_HIP_MAX_PATL_LONG", hipSuccess);
     const uint64_t base_bytes = b.packed ? (total + 3) / 4 : total;
     const uint8_t *d_bases = b.bases, *d_flags = b.nflags;
     if (b.on_device) {
@@ -529,6 +530,7 @@ static int stage_batch(real_hip_ctx *ctx, const real_hip_batch &b, Staged &s, co
     }
     s.W = (s.maxpatl + 31) / 32;
     if (s.W < 1) s.W = 1;
+    if (s.W > RH_MAXW) s.W = RH_MAXW; // (longer reads: handed over to the wave-per-read kernel)
     return REAL_HIP_OK;
 }
 

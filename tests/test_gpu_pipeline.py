@@ -107,21 +107,75 @@ def test_version_1_batch_struct_is_still_accepted():
     m.close()
 
 
-def test_under_declared_read_length_is_a_loud_error():
-    """device offsets with a caller-supplied max_patl: nothing is staged past the wave's LDS region, the call fails"""
+def test_under_declared_read_length_is_harmless():
+    """device offsets with a caller-supplied max_patl that is too small: the reads beyond it are not staged by the
+    lane-per-read kernel (nothing is written past a wave's LDS region) but handed to the wave-per-read matcher --
+    same records, only slower"""
     import torch
     g, bases, qual, offsets = _case(n_reads=3000, ragged=True)
     m = _matcher(g)
     db, dq, doff = torch.from_numpy(bases).cuda(), torch.from_numpy(qual).cuda(), torch.from_numpy(offsets.astype(np.int64)).cuda()
     n = offsets.shape[0] - 1
-    di = torch.zeros(n, dtype=torch.int64, device="cuda")
-    ds = torch.full((n,), float(np.finfo(np.float32).min), dtype=torch.float32, device="cuda")
-    with pytest.raises(rlib.RealHipError) as e:
-        m.match_unique(db, dq, doff, info=di, score=ds, max_patl=64)            # the batch holds 77 and 100 bp reads
-    assert e.value.status == rlib.REAL_HIP_E_INVALID
-    info, score = m.match_unique(db, dq, doff, info=torch.zeros_like(di), score=ds.clone(), max_patl=100)   # the true bound: fine
     ref_i, ref_s = m.match_unique(bases, qual, offsets)
-    assert np.array_equal(info.cpu().numpy().view(np.uint64), ref_i)
+    for declared in (64, 100):
+        di = torch.zeros(n, dtype=torch.int64, device="cuda")
+        ds = torch.full((n,), float(np.finfo(np.float32).min), dtype=torch.float32, device="cuda")
+        m.counters(reset=True)
+        m.match_unique(db, dq, doff, info=di, score=ds, max_patl=declared)        # the batch holds 36, 77 and 100 bp reads
+        assert np.array_equal(di.cpu().numpy().view(np.uint64), ref_i) and np.array_equal(ds.cpu().numpy().view(np.uint32), ref_s.view(np.uint32))
+        assert (m.counters()["handed_over"] > 1000) == (declared == 64)
+    m.close()
+
+
+@pytest.mark.parametrize("packed,scores", [(False, 1), (True, 1), (False, 0)])
+def test_reads_longer_than_the_registers_hold(ora, packed, scores):
+    """REAL_HIP_MAX_PATL (256) is the longest read a lane keeps in registers, not a limit of the library: longer reads
+    (up to REAL_HIP_MAX_PATL_LONG) get a wave each and are read from LDS words.  A ragged batch of 60 ... 5000 bp reads,
+    some with an N, against the oracle; then a batch of one long length."""
+    g = synth.random_genome(400_000, seed=31, n_frag=2, n_runs=3, repeats=6)
+    parts = [synth.sample_reads(g, k, pl, 0.01, seed=300 + pl, n_read_prob=0.0002) for k, pl in ((600, 100), (150, 300), (60, 257), (40, 1000), (12, 5000), (300, 60))]
+    rng = np.random.default_rng(9)
+    order = rng.permutation(sum(p.n_reads for p in parts))
+    reads = [(p.bases[int(p.offsets[i]):int(p.offsets[i + 1])], p.qual[int(p.offsets[i]):int(p.offsets[i + 1])]) for p in parts for i in range(p.n_reads)]
+    reads = [reads[i] for i in order]
+    bases = np.concatenate([r[0] for r in reads]); qual = np.concatenate([r[1] for r in reads])
+    offsets = np.concatenate([[0], np.cumsum([r[0].shape[0] for r in reads])]).astype(np.uint64)
+    assert (bases > 3).any()
+    og = ora.Genome(g.sym, g.frag_start)
+    ix = ora.Index(og, 32)
+    p = ora.make_params(seedl=32, seedkmax=2, totalkmax=5, scores=scores)
+    oinfo, oscore, octr = ora.match_unique(og, ix, p, bases, qual, offsets)
+    m = UniqueMatcher(RealOptions(seedl=32, seedkmax=2, totalkmax=5, scores=bool(scores)).normalise())
+    m.set_text_symbols(0, g.sym, g.frag_start)
+    m.build_index_block()
+    m.counters(reset=True)
+    if packed:
+        info, score = m.match_unique(synth.pack_bases(bases), qual, offsets, packed=True, nflags=synth.read_nflags(bases, offsets))
+    else:
+        info, score = m.match_unique(bases, qual, offsets)
+    assert np.array_equal(info, oinfo)
+    if scores:
+        assert np.array_equal(score.view(np.uint32), oscore.view(np.uint32))
+    c = m.counters()
+    for k in ("reads", "lookups", "candidates", "seedpass", "hits"):
+        assert c[k] == octr[k], (k, c[k], octr[k])
+    assert c["handed_over"] >= 150 + 60 + 40 + 12 - 10          # every long read (minus the ones with an N)
+    st = (info >> np.uint64(61)).astype(int)
+    lens = np.diff(offsets.astype(np.int64))
+    assert ((st[lens >= 1000] == 1) | (st[lens >= 1000] == 2)).mean() > 0.6      # long reads do align (1 % errors, k <= 5 allows few)
+    # matchAll on the same batch
+    hits, hoff = m.match_all(bases, qual, offsets)
+    ohits, ooff, _ = ora.match_all(og, ix, p, bases, qual, offsets)
+    assert np.array_equal(hoff, ooff) and np.array_equal(hits["pos"], ohits["pos"]) and np.array_equal(hits["k"], ohits["k"])
+    # one long length for the whole batch: every read goes to the wave-per-read matcher
+    b = synth.sample_reads(g, 300, 400, 0.005, seed=77)
+    oi, os_, _ = ora.match_unique(og, ix, p, b.bases, b.qual, b.offsets)
+    ui, us = m.match_unique(b.bases, b.qual, None, patl=400, n_reads=300)
+    assert np.array_equal(ui, oi) and (not scores or np.array_equal(us.view(np.uint32), os_.view(np.uint32)))
+    # beyond REAL_HIP_MAX_PATL_LONG: a loud error
+    with pytest.raises(rlib.RealHipError) as e:
+        m.match_unique(np.zeros(20000, np.uint8), np.zeros(20000, np.uint8), np.array([0, 20000], np.uint64))
+    assert e.value.status == rlib.REAL_HIP_E_UNSUPPORTED
     m.close()
 
 
