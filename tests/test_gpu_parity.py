@@ -293,8 +293,10 @@ def test_errors_are_loud():
     with pytest.raises(RealHipError):           # no index yet
         m.match_unique(np.zeros(100, np.uint8), np.zeros(100, np.uint8), patl=100)
     m.build_index_block()
-    with pytest.raises(RealHipError):           # longer than REAL_HIP_MAX_PATL: an error, not a silent skip
-        m.match_unique(np.zeros(300, np.uint8), np.zeros(300, np.uint8), patl=300)
+    with pytest.raises(RealHipError):           # longer than REAL_HIP_MAX_PATL_LONG: an error, not a silent skip
+        m.match_unique(np.zeros(17000, np.uint8), np.zeros(17000, np.uint8), patl=17000)
+    info, score = m.match_unique(np.zeros(300, np.uint8), np.zeros(300, np.uint8), patl=300)     # (longer than the registers hold: a wave's job)
+    assert info.shape[0] == 1
     # empty batch and all-skipped batch are fine
     info, score = m.match_unique(np.zeros(0, np.uint8), np.zeros(0, np.uint8), patl=100, n_reads=0)
     assert info.shape[0] == 0

@@ -133,7 +133,8 @@ def test_reads_longer_than_the_registers_hold(ora, packed, scores):
     (up to REAL_HIP_MAX_PATL_LONG) get a wave each and are read from LDS words.  A ragged batch of 60 ... 5000 bp reads,
     some with an N, against the oracle; then a batch of one long length."""
     g = synth.random_genome(400_000, seed=31, n_frag=2, n_runs=3, repeats=6)
-    parts = [synth.sample_reads(g, k, pl, 0.01, seed=300 + pl, n_read_prob=0.0002) for k, pl in ((600, 100), (150, 300), (60, 257), (40, 1000), (12, 5000), (300, 60))]
+    # (mismatches only, k <= 5: long reads get few errors, or nothing of them would align)
+    parts = [synth.sample_reads(g, k, pl, 1.5 / pl, seed=300 + pl, n_read_prob=0.02 / pl) for k, pl in ((600, 100), (150, 300), (60, 257), (40, 1000), (12, 5000), (300, 60))]
     rng = np.random.default_rng(9)
     order = rng.permutation(sum(p.n_reads for p in parts))
     reads = [(p.bases[int(p.offsets[i]):int(p.offsets[i + 1])], p.qual[int(p.offsets[i]):int(p.offsets[i + 1])]) for p in parts for i in range(p.n_reads)]
@@ -162,7 +163,7 @@ def test_reads_longer_than_the_registers_hold(ora, packed, scores):
     assert c["handed_over"] >= 150 + 60 + 40 + 12 - 10          # every long read (minus the ones with an N)
     st = (info >> np.uint64(61)).astype(int)
     lens = np.diff(offsets.astype(np.int64))
-    assert ((st[lens >= 1000] == 1) | (st[lens >= 1000] == 2)).mean() > 0.6      # long reads do align (1 % errors, k <= 5 allows few)
+    assert ((st[lens >= 1000] == 1) | (st[lens >= 1000] == 2)).mean() > 0.6      # long reads do align
     # matchAll on the same batch
     hits, hoff = m.match_all(bases, qual, offsets)
     ohits, ooff, _ = ora.match_all(og, ix, p, bases, qual, offsets)
