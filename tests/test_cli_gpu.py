@@ -178,3 +178,19 @@ def test_real_cli_known_answer_of_the_survey(tmp_path):
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     assert open(out).read() == "p207_inv\t%s\t\t1\ta\t36\t-\t random_1000000\t208\t\t0\n" % "".join("ACGT"[c] for c in sub)
     assert "timing: " in r.stderr.decode()
+
+
+def test_real_cli_reads_longer_than_256(ora, tmp_path):
+    """a read file with 300 and 700 bp reads among 100 bp ones: the long ones are matched by the wave-per-read kernel"""
+    g = synth.random_genome(120_000, seed=45, n_frag=2)
+    b = synth.concat_batches([synth.sample_reads(g, 800, 100, 0.02, seed=46), synth.sample_reads(g, 120, 300, 0.005, seed=47),
+                              synth.sample_reads(g, 30, 700, 0.002, seed=48)])
+    fa, rd = write_inputs(tmp_path, g, b, True)
+    out = str(tmp_path / "out.tsv")
+    r = subprocess.run([REAL, "-t", fa, "-p", rd, "-o", out, "-e", "3", "-s", "2", "-l", "32", "-q", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    info, score = oracle_unique(ora, g, b, 32, 2, 3, 1)
+    want = expected_unique(ora, g, b, info, score, 1)
+    got = open(out).read().split("\n")[:-1]
+    assert got == want and sum(1 for l in got if l.split("\t")[5] in ("300", "700")) > 60
