@@ -53,7 +53,7 @@ typedef enum real_hip_status {
     REAL_HIP_E_UNSUPPORTED = -6   /* e.g. read longer than REAL_HIP_MAX_PATL_LONG     */
 } real_hip_status;
 
-#define REAL_HIP_MAX_PATL 256u        /* longest read the lane-per-read kernels hold in registers                */
+#define REAL_HIP_MAX_PATL 320u        /* longest read the lane-per-read kernels hold in registers                */
 #define REAL_HIP_MAX_PATL_LONG 16384u /* longest read at all: reads beyond REAL_HIP_MAX_PATL get a wave each and are
                                          read from LDS (slower, and only those reads); longer ones are refused with
                                          REAL_HIP_E_UNSUPPORTED -- the reference has no limit (RestMatch.hpp:34-37)  */

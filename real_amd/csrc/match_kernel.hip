@@ -928,7 +928,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
 // eight translation units build in parallel instead of one for minutes)
 // ---------------------------------------------------------------------------
 #ifndef RH_W
-#error "compile with -DRH_W=<1..8>"
+#error "compile with -DRH_W=<1..10>"
 #endif
 template <int W, int TK>
 static void launch_match_wt(real_hip_ctx *ctx, const MatchArgs &a, bool all)

@@ -6,7 +6,7 @@
 #define RH_DECL_W(N)                                                                    \
     void rh_launch_match_w##N(real_hip_ctx *ctx, const MatchArgs &a, bool all);         \
     uint32_t rh_stage_bytes_w##N(int tk);
-RH_DECL_W(1) RH_DECL_W(2) RH_DECL_W(3) RH_DECL_W(4) RH_DECL_W(5) RH_DECL_W(6) RH_DECL_W(7) RH_DECL_W(8)
+RH_DECL_W(1) RH_DECL_W(2) RH_DECL_W(3) RH_DECL_W(4) RH_DECL_W(5) RH_DECL_W(6) RH_DECL_W(7) RH_DECL_W(8) RH_DECL_W(9) RH_DECL_W(10)
 void rh_launch_match_wave(real_hip_ctx *ctx, const MatchArgs &a, bool all);
 
 int rh_launch_match(real_hip_ctx *ctx, const MatchArgs &args, bool all, int state_slot)
@@ -15,10 +15,10 @@ int rh_launch_match(real_hip_ctx *ctx, const MatchArgs &args, bool all, int stat
     MatchArgs a = args;
     typedef void (*launch_fn)(real_hip_ctx *, const MatchArgs &, bool);
     typedef uint32_t (*stage_fn)(int);
-    static const launch_fn launch[8] = {rh_launch_match_w1, rh_launch_match_w2, rh_launch_match_w3, rh_launch_match_w4,
-                                        rh_launch_match_w5, rh_launch_match_w6, rh_launch_match_w7, rh_launch_match_w8};
-    static const stage_fn stage[8] = {rh_stage_bytes_w1, rh_stage_bytes_w2, rh_stage_bytes_w3, rh_stage_bytes_w4,
-                                      rh_stage_bytes_w5, rh_stage_bytes_w6, rh_stage_bytes_w7, rh_stage_bytes_w8};
+    static const launch_fn launch[RH_MAXW] = {rh_launch_match_w1, rh_launch_match_w2, rh_launch_match_w3, rh_launch_match_w4, rh_launch_match_w5,
+                                              rh_launch_match_w6, rh_launch_match_w7, rh_launch_match_w8, rh_launch_match_w9, rh_launch_match_w10};
+    static const stage_fn stage[RH_MAXW] = {rh_stage_bytes_w1, rh_stage_bytes_w2, rh_stage_bytes_w3, rh_stage_bytes_w4, rh_stage_bytes_w5,
+                                            rh_stage_bytes_w6, rh_stage_bytes_w7, rh_stage_bytes_w8, rh_stage_bytes_w9, rh_stage_bytes_w10};
     if (a.b.W < 1 || a.b.W > RH_MAXW) return rh_fail(ctx, REAL_HIP_E_UNSUPPORTED, "read longer than REAL_HIP_MAX_PATL", hipSuccess);
     int rc;
     { // reads a wave stages at a time: their bytes (+ alignment skew, pad, one dword of over-read) fit its LDS region

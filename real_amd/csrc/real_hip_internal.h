@@ -9,7 +9,8 @@
 
 #include "real_hip.h"
 
-#define RH_MAXW 8 /* 64-bit words per oriented read: REAL_HIP_MAX_PATL / 32 */
+#define RH_MAXW 10 /* 64-bit words per oriented read: REAL_HIP_MAX_PATL / 32 */
+static_assert(RH_MAXW * 32 == REAL_HIP_MAX_PATL, "one lane-per-read instance per 32 bases up to REAL_HIP_MAX_PATL");
 // Work counters are striped over this many 128-byte lines: every wave ends with a handful of atomics,
 // and 781 k waves hammering ONE line serialise at the L2 channel that owns it (measured: the whole
 // kernel then runs at the atomic rate, independent of the genome size).

@@ -32,7 +32,7 @@ void RealOptions::printHelp() const
               << "-index <device|host, where the signature lists are sorted, default=device>\n"
               << "-block <positions per index block, default=as many as fit>\n-batch <reads per device batch>\n"
               << "-gpuparse <parse the read file on the device, default=1>\n-chunk <bytes of read-file text per device call, default=268435456>\n"
-              << "Reads longer than 16384 bases are refused (the reference has no such limit); reads longer than 256 bases are slow.\n";
+              << "Reads longer than 16384 bases are refused (the reference has no such limit); reads longer than 320 bases are slow.\n";
 }
 
 // The hand-rolled argv loop of RealOptions.cpp:140-396: "-x value" pairs, unknown arguments are

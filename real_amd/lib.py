@@ -22,7 +22,7 @@ REAL_HIP_E_DEVICE = -3
 REAL_HIP_E_OVERFLOW = -4
 REAL_HIP_E_STATE = -5
 REAL_HIP_E_UNSUPPORTED = -6
-REAL_HIP_MAX_PATL = 256
+REAL_HIP_MAX_PATL = 320
 REAL_HIP_MAX_PATL_LONG = 16384
 
 K_MATCH_UNIQUE, K_MATCH_ALL, K_ALL_SORT, K_INDEX, K_MATCH_REPEAT, K_PARSE = range(6)

@@ -180,8 +180,8 @@ def test_real_cli_known_answer_of_the_survey(tmp_path):
     assert "timing: " in r.stderr.decode()
 
 
-def test_real_cli_reads_longer_than_256(ora, tmp_path):
-    """a read file with 300 and 700 bp reads among 100 bp ones: the long ones are matched by the wave-per-read kernel"""
+def test_real_cli_long_reads(ora, tmp_path):
+    """a read file with 300 and 700 bp reads among 100 bp ones: 300 bp still fit a lane's registers, 700 bp are matched by the wave-per-read kernel"""
     g = synth.random_genome(120_000, seed=45, n_frag=2)
     b = synth.concat_batches([synth.sample_reads(g, 800, 100, 0.02, seed=46), synth.sample_reads(g, 120, 300, 0.005, seed=47),
                               synth.sample_reads(g, 30, 700, 0.002, seed=48)])

@@ -129,12 +129,12 @@ def test_under_declared_read_length_is_harmless():
 
 @pytest.mark.parametrize("packed,scores", [(False, 1), (True, 1), (False, 0)])
 def test_reads_longer_than_the_registers_hold(ora, packed, scores):
-    """REAL_HIP_MAX_PATL (256) is the longest read a lane keeps in registers, not a limit of the library: longer reads
+    """REAL_HIP_MAX_PATL (320) is the longest read a lane keeps in registers, not a limit of the library: longer reads
     (up to REAL_HIP_MAX_PATL_LONG) get a wave each and are read from LDS words.  A ragged batch of 60 ... 5000 bp reads,
     some with an N, against the oracle; then a batch of one long length."""
     g = synth.random_genome(400_000, seed=31, n_frag=2, n_runs=3, repeats=6)
     # (mismatches only, k <= 5: long reads get few errors, or nothing of them would align)
-    parts = [synth.sample_reads(g, k, pl, 1.5 / pl, seed=300 + pl, n_read_prob=0.02 / pl) for k, pl in ((600, 100), (150, 300), (60, 257), (40, 1000), (12, 5000), (300, 60))]
+    parts = [synth.sample_reads(g, k, pl, 1.5 / pl, seed=300 + pl, n_read_prob=0.02 / pl) for k, pl in ((600, 100), (150, 400), (60, 321), (40, 1000), (12, 5000), (300, 60), (100, 300))]
     rng = np.random.default_rng(9)
     order = rng.permutation(sum(p.n_reads for p in parts))
     reads = [(p.bases[int(p.offsets[i]):int(p.offsets[i + 1])], p.qual[int(p.offsets[i]):int(p.offsets[i + 1])]) for p in parts for i in range(p.n_reads)]
@@ -169,9 +169,9 @@ def test_reads_longer_than_the_registers_hold(ora, packed, scores):
     ohits, ooff, _ = ora.match_all(og, ix, p, bases, qual, offsets)
     assert np.array_equal(hoff, ooff) and np.array_equal(hits["pos"], ohits["pos"]) and np.array_equal(hits["k"], ohits["k"])
     # one long length for the whole batch: every read goes to the wave-per-read matcher
-    b = synth.sample_reads(g, 300, 400, 0.005, seed=77)
+    b = synth.sample_reads(g, 300, 420, 0.005, seed=77)
     oi, os_, _ = ora.match_unique(og, ix, p, b.bases, b.qual, b.offsets)
-    ui, us = m.match_unique(b.bases, b.qual, None, patl=400, n_reads=300)
+    ui, us = m.match_unique(b.bases, b.qual, None, patl=420, n_reads=300)
     assert np.array_equal(ui, oi) and (not scores or np.array_equal(us.view(np.uint32), os_.view(np.uint32)))
     # beyond REAL_HIP_MAX_PATL_LONG: a loud error
     with pytest.raises(rlib.RealHipError) as e:

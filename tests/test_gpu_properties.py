@@ -97,10 +97,10 @@ def test_match_all_properties_mid_size(ora):
 
 
 def test_ragged_max_length_and_edge_reads(ora):
-    """reads of 32..256 bp in one batch (256 = REAL_HIP_MAX_PATL), reads at the very ends of fragments,
+    """reads of 32..320 bp in one batch (320 = REAL_HIP_MAX_PATL), reads at the very ends of fragments,
     reads equal to the seed length, reads with N, reads shorter than the seed."""
     g = synth.random_genome(300_000, seed=81, n_frag=6, n_runs=10)
-    parts = [synth.sample_reads(g, 300, L, 0.02, seed=82 + L, n_read_prob=0.001) for L in (32, 33, 64, 127, 128, 129, 200, 256)]
+    parts = [synth.sample_reads(g, 300, L, 0.02, seed=82 + L, n_read_prob=0.001) for L in (32, 33, 64, 127, 128, 129, 200, 256, 257, 289, 320)]
     parts.append(synth.sample_reads(g, 50, 20, 0.0, seed=99))            # shorter than the seed: skipped
     # reads ending exactly at a fragment end / starting at a fragment start
     edge_b, edge_q, edge_o = [], [], [0]
