@@ -31,12 +31,14 @@ txt = subprocess.run([sys.executable, os.path.join(ROOT, "bench_support", "parse
                      stdout=subprocess.PIPE, check=True).stdout.decode()
 open(os.path.join(out, rnd + "_counters.txt"), "w").write("# per-launch averages of `%s`\n" % sel + txt)
 
-pmc = collections.defaultdict(list)
+pmc, shuf = collections.defaultdict(list), collections.defaultdict(list)
 for f in glob.glob(os.path.join(pdir, "*", "*_counter_collection.csv")):
+    into = shuf if os.path.basename(os.path.dirname(f)).endswith("_shuffled") else pmc        # (the pass on shuffled reads is a figure of its own)
     for r in csv.DictReader(open(f)):
         if sel in r["Kernel_Name"]:
-            pmc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            into[r["Counter_Name"]].append(float(r["Counter_Value"]))
 avg = {k: sum(v) / len(v) for k, v in pmc.items()}
+avg_shuf = {k: sum(v) / len(v) for k, v in shuf.items()}
 hbm = 2 * avg["FETCH_SIZE"] * 1024 + avg["WRITE_SIZE"] * 1024
 sys.path.insert(0, ROOT)
 import bench as bench_py
@@ -48,6 +50,7 @@ tj = {key: {
     "correction": "reads = 2 x FETCH_SIZE x 1024 (gfx950: requests tallied at 64 B, L2 lines are 128 B; MI355X_MICROARCH.md "
                   "section HBM), writes = WRITE_SIZE x 1024; separate --pmc passes (bench_support/profile.sh)",
     "TCC_MISS_per_launch": avg.get("TCC_MISS_sum"), "TCC_REQ_per_launch": avg.get("TCC_REQ_sum"),
+    "TCC_MISS_per_launch_shuffled_reads": avg_shuf.get("TCC_MISS_sum"),
     "avg_launch_ms_under_trace": avg_ms, "launches_under_trace": calls}}
 json.dump(tj, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 print(json.dumps(tj[key], indent=1))
