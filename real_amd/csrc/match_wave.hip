@@ -124,6 +124,7 @@ __device__ __forceinline__ WaveRange wave_lookup(const MatchArgs &a, uint64_t sh
 // The read sits in the wave's LDS as words of 32 bases, straight and reverse-complemented; every lane walks the words of
 // its own candidate in run-time loops (an LDS word is the same address in all lanes: a broadcast).
 #define WV_NWL (REAL_HIP_MAX_PATL_LONG / 32u)
+#define WV_QL 2048u
 
 // word j of the read (32 bases, MSB first) from the batch; *bad is set if a base is > 3 (byte input)
 __device__ __forceinline__ uint64_t long_word(const MatchArgs &a, uint64_t o0, uint32_t patl, uint32_t j, bool *bad)
@@ -197,6 +198,7 @@ __global__ __launch_bounds__(256) void match_wave_kernel(MatchArgs a)
     constexpr int W = WV_W;
     __shared__ double sLL[SCORES ? RH_LL_SLOTS : 1];
     __shared__ uint64_t sLong[4][2][WV_NWL]; // per wave: the words of a long read, straight and reverse-complemented
+    __shared__ uint8_t sQual[4][WV_QL];       // ... and its qualities, if it has at most WV_QL bases (longer: from global memory)
     if (SCORES) {
         for (int i = threadIdx.x; i < 1024; i += 256) sLL[i] = a.LL[i];
         if (threadIdx.x == 0) sLL[RH_LL_ZERO] = 0.0;
@@ -230,6 +232,8 @@ __global__ __launch_bounds__(256) void match_wave_kernel(MatchArgs a)
             __builtin_amdgcn_wave_barrier();
             bool bad = false;
             for (uint32_t j = lane; j < nw; j += 64) sO[j] = long_word(a, o0, patl, j, &bad);
+            if (SCORES && a.b.qual && patl <= WV_QL) // the scoring loop reads a quality per base: from LDS, not one global load each
+                for (uint32_t i = lane; i < patl; i += 64) sQual[threadIdx.x >> 6][i] = a.b.qual[o0 + i];
             elig = !__any(bad);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -341,7 +345,9 @@ __global__ __launch_bounds__(256) void match_wave_kernel(MatchArgs a)
                             if (total <= a.totalkmax) {
                                 hit = true;
                                 cH++; // one updater::update call per list, match.hpp:411
-                                if (SCORES) sc = long_score(sLL, T, cur, pos, patl, a.b.qual ? a.b.qual + o0 : nullptr, (uint32_t)inv);
+                                if (SCORES)
+                                    sc = long_score(sLL, T, cur, pos, patl, !a.b.qual ? nullptr : (patl <= WV_QL ? (const uint8_t *)sQual[threadIdx.x >> 6] : a.b.qual + o0),
+                                                    (uint32_t)inv);
                                 first = (z0 && z1) ? 0u : (z0 && z2) ? 1u : (z0 && z3) ? 2u : (z1 && z2) ? 3u : (z1 && z3) ? 4u : 5u;
                             }
                         } else if (ok) {
