@@ -175,7 +175,9 @@ typedef struct real_hip_batch {
     uint32_t        packed;     /* 1: bases holds 2 bits per base instead of a byte: base g of the
                                    concatenated batch at bits 7-2(g%4)-1.. of byte g/4 (MSB first, the
                                    packing of TemporaryFile.hpp:335-373); offsets / patl still count bases */
-    uint32_t        reserved;
+    uint32_t        fresh;      /* matchUnique: 1 = the records start as uniqueinfo(numpat) does (NoMatch, score -FLT_MAX,
+                                   matchUniqueImplementation.cpp:1094-1097, UniqueMatchInfo.hpp:191) and info / score are
+                                   outputs only -- the first genome block of a run; 0 = in/out, folds compose          */
     const uint8_t  *nflags;     /* packed only, nullable: bit (i%8) of byte i/8 set => read i holds a symbol
                                    > 3 (it cannot be packed) and is skipped as the reference skips it
                                    (matchUniqueImplementation.cpp:376-394)                              */

@@ -875,10 +875,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
     wave_lds_sync();
     // ---- match
     s.r = r; s.patl = patl; s.p_n = 0; s.nhit = 0;
-    if (elig && !ALL) {
+    if (elig && !ALL && !a.b.fresh) {
         s.info = a.info[r];
         if (SCORES) s.iscore = a.score[r];
     }
+    if (!ALL && a.b.fresh) s.iscore = -3.402823466e+38f; // uniqueinfo(numpat): NoMatch (info 0), score -FLT_MAX (UniqueMatchInfo.hpp:191)
     if (TK >= 3) // bucket rows: lookups by lane groups, the whole wave comes along
         match_read_rows<W, SCORES, ALL, DEFER, TK == 4>(a, s, sLL, stg, elig);
     else if (elig)
@@ -909,6 +910,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
             a.info[r] = s.info;
             if (SCORES) a.score[r] = s.iscore;
         }
+    } else if (!ALL && a.b.fresh && r < n) { // skipped or handed over: the record starts here (the wave matcher folds into it)
+        a.info[r] = 0;
+        if (SCORES) a.score[r] = -3.402823466e+38f;
     }
     if (ALL && r < n) a.hit_cnt[r] = (elig && !ovf) ? s.nhit : 0u; // (a handed-over read: the wave matcher writes it)
 

@@ -571,17 +571,17 @@ extern "C" int real_hip_match_unique(real_hip_ctx *ctx, const real_hip_batch *b,
     float *d_score = score;
     if (b->on_device != 1) { // outputs in host memory
         if ((rc = rh_reserve(ctx, ctx->s_info, n * 8))) return rc;
-        RH_HIP(ctx, hipMemcpyAsync(ctx->s_info.p, info, n * 8, hipMemcpyHostToDevice, ctx->stream));
+        if (!b->fresh) RH_HIP(ctx, hipMemcpyAsync(ctx->s_info.p, info, n * 8, hipMemcpyHostToDevice, ctx->stream));
         d_info = (uint64_t *)ctx->s_info.p;
         if (sc) {
             if ((rc = rh_reserve(ctx, ctx->s_score, n * 4))) return rc;
-            RH_HIP(ctx, hipMemcpyAsync(ctx->s_score.p, score, n * 4, hipMemcpyHostToDevice, ctx->stream));
+            if (!b->fresh) RH_HIP(ctx, hipMemcpyAsync(ctx->s_score.p, score, n * 4, hipMemcpyHostToDevice, ctx->stream));
             d_score = (float *)ctx->s_score.p;
         }
     }
     MatchArgs a;
     fill_args(ctx, s, n, a);
-    a.info = d_info; a.score = d_score;
+    a.info = d_info; a.score = d_score; a.b.fresh = b->fresh ? 1u : 0u;
     if ((rc = rh_launch_match(ctx, a, false, 2))) return rc;
     if (b->on_device != 1) { // outputs in host memory
         RH_HIP(ctx, hipMemcpyAsync(info, d_info, n * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -627,10 +627,7 @@ static int submit_unique(real_hip_ctx *ctx, RhSlot &S, int slot, const real_hip_
     // uniqueinfo(numpat), matchUniqueImplementation.cpp:1094-1097 -- NoMatch, score -FLT_MAX)
     if ((rc = rh_reserve(ctx, S.info, n * 8))) return rc;
     if (sc && (rc = rh_reserve(ctx, S.score, n * 4))) return rc;
-    if (fresh) {
-        RH_HIP(ctx, hipMemsetAsync(S.info.p, 0, n * 8, ctx->copy_stream));
-        if (sc) hipLaunchKernelGGL(fill_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->copy_stream, (float *)S.score.p, n, -3.402823466e+38f);
-    } else {
+    if (!fresh) { // (fresh: the kernel starts every record itself)
         RH_HIP(ctx, hipMemcpyAsync(S.info.p, info, n * 8, hipMemcpyHostToDevice, ctx->copy_stream));
         if (sc) RH_HIP(ctx, hipMemcpyAsync(S.score.p, score, n * 4, hipMemcpyHostToDevice, ctx->copy_stream));
     }
@@ -638,7 +635,7 @@ static int submit_unique(real_hip_ctx *ctx, RhSlot &S, int slot, const real_hip_
     if ((rc = stage_batch(ctx, bv, s, StageBufs{&S.bases, &S.qual, &S.off, &S.nflags}, ctx->copy_stream, S.up))) return rc;
     MatchArgs a;
     fill_args(ctx, s, n, a);
-    a.info = (uint64_t *)S.info.p; a.score = (float *)S.score.p;
+    a.info = (uint64_t *)S.info.p; a.score = (float *)S.score.p; a.b.fresh = (fresh || bv.fresh) ? 1u : 0u;
     if ((rc = rh_launch_match(ctx, a, false, slot))) return rc;
     RH_HIP(ctx, hipEventRecord(S.matched, ctx->stream));
     RH_HIP(ctx, hipStreamWaitEvent(ctx->down_stream, S.matched, 0));

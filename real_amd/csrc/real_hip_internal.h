@@ -88,6 +88,7 @@ struct DevBatch {
     // > 3 and is skipped
     uint32_t packed;
     const uint8_t *nflags;
+    uint32_t fresh;        // matchUnique: the records are not read, every read of the batch starts as NoMatch / -FLT_MAX
 };
 
 struct MatchArgs {

@@ -537,6 +537,7 @@ int matchUnique(const RealOptions &o)
                     const double tm = now_s();
                     onEach(ch.size(), [&](size_t g) {
                         real_hip_batch rb = makeBatch(pr[g]);
+                        rb.fresh = !counted; // first pass over the reads: the records start on the device
                         if (rb.n_reads)
                             check(ctx[g]->h, real_hip_match_unique(ctx[g]->h, &rb, info.data() + first_id[g], o.scores ? score.data() + first_id[g] : nullptr),
                                   "real_hip_match_unique");
@@ -549,6 +550,7 @@ int matchUnique(const RealOptions &o)
                     const double tm = now_s();
                     onEach(used, [&](size_t g) {
                         real_hip_batch rb = makeBatch(blk[g]);
+                        rb.fresh = !counted;
                         if (rb.n_reads)
                             check(ctx[g]->h, real_hip_match_unique(ctx[g]->h, &rb, info.data() + blk[g].first_id, o.scores ? score.data() + blk[g].first_id : nullptr),
                                   "real_hip_match_unique");

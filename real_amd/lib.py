@@ -50,7 +50,7 @@ class RealHipBatch(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("on_device", C.c_uint32), ("n_reads", C.c_uint64),
                 ("bases", C.c_void_p), ("qual", C.c_void_p), ("offsets", C.c_void_p),
                 ("patl", C.c_uint32), ("max_patl", C.c_uint32),
-                ("packed", C.c_uint32), ("reserved", C.c_uint32), ("nflags", C.c_void_p)]
+                ("packed", C.c_uint32), ("fresh", C.c_uint32), ("nflags", C.c_void_p)]
 
 
 class RealHipParsed(C.Structure):

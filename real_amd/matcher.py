@@ -269,9 +269,11 @@ class HipMatcher:
         return b
 
     def match_unique(self, bases, qual, offsets=None, patl: int = 0, info=None, score=None,
-                     n_reads: Optional[int] = None, max_patl: int = 0, packed: bool = False, nflags=None):
+                     n_reads: Optional[int] = None, max_patl: int = 0, packed: bool = False, nflags=None,
+                     fresh: bool = False):
         """UniqueMatcher::match over a pattern block, folding into info/score in place.
-        Host numpy arrays or device torch tensors (all of one kind)."""
+        Host numpy arrays or device torch tensors (all of one kind).  fresh: info / score are outputs only, every
+        record starts as uniqueinfo(numpat) does (the first genome block of a run)."""
         if isinstance(bases, np.ndarray):
             bases = np.ascontiguousarray(bases, dtype=np.uint8)
             qual = None if qual is None else np.ascontiguousarray(qual, dtype=np.uint8)
@@ -281,6 +283,7 @@ class HipMatcher:
         b = self._batch(bases, qual, offsets, patl, n_reads, max_patl)
         b.packed = int(bool(packed))
         b.nflags = _ptr(nflags)
+        b.fresh = int(bool(fresh))
         if info is None:
             info, score = new_unique_info(int(b.n_reads), self.opts.scores)
         self.sync_inputs(bases, qual, offsets, info, score)

@@ -372,6 +372,33 @@ def test_repeat_cliff_is_bit_exact_and_bounded_in_time(ora, seedl, kind, pb, sco
     m.close()
 
 
+@pytest.mark.parametrize("where", ["host", "device"])
+def test_fresh_batch_ignores_what_the_record_arrays_hold(ora, where):
+    """real_hip_batch.fresh: info / score are outputs only; every read -- matched by a lane, handed to the wave matcher
+    (the poly-A reads), skipped (N reads, short reads) -- starts as uniqueinfo(numpat) does (UniqueMatchInfo.hpp:191)."""
+    g, bases, qual, offsets, patl = _repeat_cliff_case(16, 20_000, 5_000)
+    bases = bases.copy()
+    bases[5 * patl + 3] = 4                                  # a read with an N: not matched at all
+    p = ora.make_params(seedl=16, seedkmax=2, totalkmax=3, scores=1)
+    oinfo, oscore, _ = _oracle_unique(ora, None, g.sym, g.frag_start, 16, 0, p, bases, qual, offsets)
+    m = UniqueMatcher(_opts(16, 2, 3, 1), prefix_bits=13, table_kind=3)
+    m.set_text_symbols(0, g.sym, g.frag_start)
+    m.build_index_block()
+    n = offsets.shape[0] - 1
+    info = np.full(n, 0x7123456789abcdef, dtype=np.uint64)   # garbage that would win every fold
+    score = np.full(n, 1e30, dtype=np.float32)
+    if where == "device":
+        import torch
+        d = [torch.from_numpy(x).cuda() for x in (bases, qual, offsets.view(np.int64), info.view(np.int64), score)]
+        m.match_unique(d[0], d[1], d[2], info=d[3], score=d[4], fresh=True)
+        info, score = d[3].cpu().numpy().view(np.uint64), d[4].cpu().numpy()
+    else:
+        m.match_unique(bases, qual, offsets, info=info, score=score, fresh=True)
+    assert m.counters()["handed_over"] > 0
+    _compare_unique(info, score, oinfo, oscore, 1)
+    m.close()
+
+
 @pytest.mark.parametrize("seedl,kind,pb", [(32, 0, 0), (16, 3, 13)])
 def test_repeat_cliff_match_all(ora, seedl, kind, pb):
     """matchAll on the same case: 10^5 hits per read.  The wave-cooperative matcher appends them behind ballots, the
