@@ -416,8 +416,13 @@ def main():
         dist.all_reduce(t)
         world_seen = int(t.item())
         assert world_seen == dist.get_world_size() == world
-    dist_info = {"world_size": world_seen, "backend": ("rccl" if backend == "nccl" else backend),
-                 "rccl_version": (".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None)}
+    rccl_version = None
+    if backend == "nccl":
+        try:
+            rccl_version = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception as e:      # (a label only: never worth the run)
+            rccl_version = "unknown (%r)" % (e,)
+    dist_info = {"world_size": world_seen, "backend": ("rccl" if backend == "nccl" else backend), "rccl_version": rccl_version}
 
     t_start = time.time()
 

@@ -37,7 +37,8 @@ if mode == "unique":
 else:
     dt, ctr, kt, nh, _, _ = bench.timed_all(torch, None, m, rlib, bases, qual, patl, n, %(steps)d, 2, 1, 0, dev, dev)
     ms, ln = kt["match"]; rms, rn = kt["repeat"]
-print(json.dumps({"kernel_ms": ms / max(ln, 1), "wave_pass_ms": rms / max(rn, 1), "ms_per_step": dt / %(steps)d * 1e3, "hits_per_read": ctr["hits"] / max(ctr["reads"], 1)}))
+print(json.dumps({"kernel_ms": ms / max(ln, 1), "wave_pass_ms": rms / max(rn, 1), "ms_per_step": dt / %(steps)d * 1e3, "hits_per_read": ctr["hits"] / max(ctr["reads"], 1),
+                  "per_wave": {k: v / max(ctr["reads"] / 64.0, 1) for k, v in ctr.items()}}))
 '''
 
 
@@ -67,6 +68,10 @@ def main():
             j = json.loads([x for x in p.stdout.splitlines() if x.startswith("{")][-1])
             res[l].append(j)
             print("round %d %-50s kernel %.3f ms  step %.3f ms  wave pass %.3f ms" % (r, os.path.basename(l), j["kernel_ms"], j["ms_per_step"], j["wave_pass_ms"]), flush=True)
+            if "phase" in os.path.basename(l):   # a -DRH_PHASE_TIMING=1 build: the counters are ticks of 10 ns per wave
+                pw = j["per_wave"]
+                print("        per wave, us: front %.2f  waiting for rows %.2f  decoding %.2f  draining %.2f  staging qualities %.2f  scoring %.2f  whole wave %.2f" % tuple(
+                    pw[k] / 100.0 for k in ("lookups", "probes", "candidates", "seedpass", "hits", "verified", "handed_over")), flush=True)
     print(json.dumps({os.path.basename(l): {"kernel_ms": [x["kernel_ms"] for x in v], "mean": sum(x["kernel_ms"] for x in v) / max(len(v), 1)} for l, v in res.items()}))
 
 

@@ -36,6 +36,17 @@
 #ifndef RH_ABLATE
 #define RH_ABLATE 0
 #endif
+// RH_PHASE_TIMING (experimental builds only): the work counters L,P,C,S,H,V and handed_over are replaced by the time
+// (ticks of 10 ns, summed over the waves) spent in: front, waiting for rows, decoding rows, draining queues (verification),
+// staging qualities, scoring + delivering, and the whole wave
+#ifndef RH_PHASE_TIMING
+#define RH_PHASE_TIMING 0
+#endif
+#if RH_PHASE_TIMING
+#define PH_NOW() ((unsigned)__builtin_amdgcn_s_memrealtime())
+#else
+#define PH_NOW() 0u
+#endif
 #define EB 8  // index entries a lane requests per round trip while enumerating equal ranges
 #define MQ 16 // candidate queue slots per lane (LDS); a full queue is drained and refilled
 // LDS bytes of one wave: its candidate queue (MQ x 64 positions + lists, 6 x 64 cursors; the first 6.5 KiB) while
@@ -64,11 +75,14 @@ struct LaneState {
     // read
     uint64_t O[W];      // oriented read, 32 bases per word
     uint64_t shi, slo;  // seed halves (m0|m1), (m2|m3) of the oriented read
-    uint32_t patl, nw, so;
-    uint64_t lastmask;
-    float eps;
+    uint32_t patl;
     int inv;
-    uint64_t r, o0;     // read index; offset of its bytes in the batch arrays
+    // (derived from patl / inv where they are needed instead of being carried along: registers)
+    __device__ __forceinline__ uint32_t nw() const { return (patl + 31) >> 5; }                                            // words of 32 bases
+    __device__ __forceinline__ uint64_t lastmask() const { return ~0ull << (64 - 2 * (patl - 32 * (nw() - 1))); }          // the bases of the last word
+    __device__ __forceinline__ uint32_t so(uint32_t l) const { return inv ? (patl - l) : 0u; }                             // RestMatch::getMatchOffset, RestMatch.hpp:84-89
+    __device__ __forceinline__ float eps(double filter_mult) const { return (float)(filter_mult * (double)patl); }         // RealOptions.hpp:74-77
+    uint64_t r, o0, o1; // read index; offsets of its first byte and of the byte behind its last one in the batch arrays
     // result
     uint64_t info;
     float iscore;
@@ -85,8 +99,19 @@ struct LaneState {
                                           // longer ones read the text again when they score: the registers are worth more)
     uint32_t p_n, p_nev, p_ev, cslot;     // locations, events, 1 bit per event (= location), slot of the memo
     uint32_t nhit; // matchAll: hits appended for this read
-    // work counters
-    unsigned cL, cP, cC, cS, cH, cV;
+    // work counters of this read, packed (a register each would cost six of the 168): cA = L:4 | V:12 | S:12, cB = P:11 | C:11 | H:10.
+    // No field overflows without the read being handed over -- a lane walks at most BIG_T entries of each of its 12 equal
+    // ranges (plus a binary search) -- and a read that is handed over counts for nothing here (the wave matcher counts it).
+    unsigned cA, cB;
+    __device__ __forceinline__ void addL(unsigned n) { cA += n; }
+    __device__ __forceinline__ void addV(unsigned n) { cA += n << 4; }
+    __device__ __forceinline__ void addS(unsigned n) { cA += n << 16; }
+    __device__ __forceinline__ void addP(unsigned n) { cB += n; }
+    __device__ __forceinline__ void addC(unsigned n) { cB += n << 11; }
+    __device__ __forceinline__ void addH(unsigned n) { cB += n << 22; }
+#if RH_PHASE_TIMING
+    unsigned tW, tD, tR; // ticks of 10 ns this wave spent waiting for rows, decoding them, draining its queues
+#endif
 };
 
 
@@ -99,7 +124,7 @@ __device__ __forceinline__ void deliver(const MatchArgs &a, LaneState<W, SCORES,
         if (slot < a.raw_cap) a.raw[slot] = make_uint4((uint32_t)s.r, pos, __float_as_uint(score), meta);
         s.nhit++;
     } else {
-        fold_update<SCORES>((meta >> 8) & 1, a.t.fileid, pos, meta & 0xff, score, s.eps, meta >> 16, s.info, s.iscore);
+        fold_update<SCORES>((meta >> 8) & 1, a.t.fileid, pos, meta & 0xff, score, s.eps(a.filter_mult), meta >> 16, s.info, s.iscore);
     }
 }
 
@@ -135,7 +160,7 @@ __device__ __forceinline__ void flush_pending(const MatchArgs &a, LaneState<W, S
 #pragma unroll
             for (int i = 0; i <= W; i += 2) {
                 U64x2 p2 = {0ull, 0ull};
-                if ((uint32_t)i <= s.nw) p2 = load2(a.t.text + wi + i);
+                if ((uint32_t)i <= s.nw()) p2 = load2(a.t.text + wi + i);
                 t[i] = p2.a; t[i + 1] = p2.b;
             }
 #pragma unroll
@@ -196,17 +221,18 @@ __device__ __forceinline__ void process_candidate(const MatchArgs &a, LaneState<
                                       (z1 && z3 ? 16u : 0u) | (z2 && z3 ? 32u : 0u));
     if (!members) return;
     const uint32_t nm = __popc(members);
-    if (!a.ix.pbits) s.cC += nm; // (with partner bits the entry holds the whole signature: counted at the scan)
+    if (!a.ix.pbits) s.addC(nm); // (with partner bits the entry holds the whole signature: counted at the scan)
     const unsigned seedk = k0 + k1 + k2 + k3; // = diffcountpair(s_b, list_b[p->ptr].sign), match.hpp:386
     if (seedk > a.seedkmax) return;
-    s.cS += nm;
-    if (rpos < s.so) return; // match.hpp:393
-    const uint32_t pos = rpos - s.so;
+    s.addS(nm);
+    const uint32_t so = s.so(a.l);
+    if (rpos < so) return; // match.hpp:393
+    const uint32_t pos = rpos - so;
     bool reg = false; // a location verified here for the first time
     if (pos != s.cpos) {
         s.cpos = pos;
         s.cok = false;
-        s.cV++;
+        s.addV(1u);
         uint32_t frag;
         if (!frag_valid(a.t, pos, s.patl, frag)) return;
         if (a.t.has_wild && !wild_free(a.t.wild, pos, s.patl)) return;
@@ -216,12 +242,14 @@ __device__ __forceinline__ void process_candidate(const MatchArgs &a, LaneState<
         const unsigned sh = 2u * (pos & 31);
         uint64_t tw[W];
         unsigned total = 0;
+        const uint32_t nw = s.nw();
+        const uint64_t lastmask = s.lastmask();
         {
             uint64_t t[W + 2];
 #pragma unroll
             for (int j = 0; j <= W; j += 2) { // 16-byte requests, all in flight together
                 U64x2 p2 = {0ull, 0ull};
-                if ((uint32_t)j <= s.nw) p2 = load2(T + wi + j);
+                if ((uint32_t)j <= nw) p2 = load2(T + wi + j);
                 t[j] = p2.a; t[j + 1] = p2.b;
             }
 #pragma unroll
@@ -230,8 +258,8 @@ __device__ __forceinline__ void process_candidate(const MatchArgs &a, LaneState<
                 tw[j] = al;
                 uint64_t x = al ^ s.O[j];
                 uint64_t d = ((x >> 1) | x) & M55;
-                if ((uint32_t)j + 1 == s.nw) d &= s.lastmask;
-                if ((uint32_t)j < s.nw) total += __popcll(d);
+                if ((uint32_t)j + 1 == nw) d &= lastmask;
+                if ((uint32_t)j < nw) total += __popcll(d);
             }
         }
         if (total > a.totalkmax) return;
@@ -254,7 +282,7 @@ __device__ __forceinline__ void process_candidate(const MatchArgs &a, LaneState<
     }
     (void)reg;
     if (!s.cok) return;
-    s.cH += nm; // one updater::update call per list, match.hpp:411
+    s.addH(nm); // one updater::update call per list, match.hpp:411
     uint32_t events = members;
     if (ALL) {
         // unifyMatches (matchAllImplementation.cpp:150-161) only removes exact duplicates: the same
@@ -315,14 +343,14 @@ __device__ __forceinline__ void scan_lists(const MatchArgs &a, LaneState<W, SCOR
     }
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-        s.cL++;
+        s.addL(1u);
         cur[i] = lo[i];
         if (hi[i] - lo[i] > 16) { // large bucket: lower_bound on the key first
             const uint2 *__restrict__ E = a.ix.ent[LA0 + i];
             uint32_t x = lo[i], y = hi[i];
             while (x < y) {
                 uint32_t mid = x + ((y - x) >> 1);
-                s.cP++;
+                s.addP(1u);
                 if ((E[mid].x >> pbits) < fp[i]) x = mid + 1; else y = mid;
             }
             cur[i] = x;
@@ -347,7 +375,7 @@ __device__ __forceinline__ void scan_lists(const MatchArgs &a, LaneState<W, SCOR
                 if (j == lo[i]) e = e0[i];
                 else if (j == lo[i] + 1) e = e1[i];
                 else e = E[j];
-                s.cP++;
+                s.addP(1u);
                 const uint32_t ek = e.x >> pbits;
                 if (ek > f) break;
                 if (ek == f) {
@@ -356,7 +384,7 @@ __device__ __forceinline__ void scan_lists(const MatchArgs &a, LaneState<W, SCOR
                         // member of the reference's equal range; seed popcount filter (match.hpp:386) on the
                         // partner symbols the entry carries: more than seedkmax known mismatches => rejected
                         // without touching the text (exact: the full count can only be larger)
-                        s.cC++;
+                        s.addC(1u);
                         const uint32_t x = (e.x & pmask) ^ rp;
                         keep = __popc(((x >> 1) | x) & 0x55555555u) <= a.seedkmax;
                     }
@@ -435,7 +463,7 @@ __device__ __forceinline__ void match_lists_fine(const MatchArgs &a, LaneState<W
                     while (x < y) { uint32_t mid = x + ((y - x) >> 1); if (E[mid].x <= rp[i]) x = mid + 1; else y = mid; }
                     sz = x - start;
                 }
-                s.cP += sz;
+                s.addP(sz);
             } else {
             // the entry's 96 bits = 8 fields {size:4, digest:8}, field g = key group g of the bucket
             const uint32_t fi = f[i];
@@ -471,10 +499,10 @@ __device__ __forceinline__ void match_lists_fine(const MatchArgs &a, LaneState<W
             }
             if (sz > BIG_T) s.p_n = PEND_OVF; // a long equal range is walked by a whole wave (match_wave.hip)
             lo[i] = start; cum[i] = total; total += sz;
-            s.cL++;
+            s.addL(1u);
         }
     }
-    s.cC += counted; s.cP += counted;
+    s.addC(counted); s.addP(counted);
     // 2. enumerate, filter, queue, drain
     for (uint32_t kb = 0; kb < total && !(s.p_n == PEND_OVF); kb += MQ) {
         const uint32_t kend = min(total, kb + (uint32_t)MQ);
@@ -563,9 +591,32 @@ __device__ __forceinline__ void wave_lds_sync()
 // of 32: four load instructions, the rows go to LDS, then the 32 owner lanes read their row's directory and
 // -- from the same row -- the entries of their key group, apply the partner filter and queue the survivors
 // with their positions.  The loads of the next list are in flight while this one is decoded.  The queue is
-// drained by every lane for itself, in list order, when one is full and at the end.
+// drained by every lane for itself, in list order, behind the last list.
+// Qualities ahead of time (bucket rows, scores on): a wave whose 64 reads are one staging group, whose quality bytes start
+// at a multiple of 16 and fit the place of the rows, has them brought there by LDS-DMA while it drains its queues for the
+// last time.  Decided from the offsets of the reads alone, at both places that need to know (nothing is carried along:
+// the scalar registers are all in use).
+__device__ __forceinline__ bool quals_ahead(const MatchArgs &a, uint64_t o0, uint64_t o1, const uint8_t *&src, uint32_t &nbytes)
+{
+    if (!a.b.qual || a.b.gl < 64) return false;
+    const uint64_t gb = __shfl(o0, 0), ge = __shfl(o1, 63);
+    src = a.b.qual + gb;
+    nbytes = (uint32_t)(ge - gb);
+    return ge >= gb && ge - gb <= 64u * 128u && ((uintptr_t)src & 15u) == 0;
+}
+
+// every byte that quals_ahead()'s LDS-DMA brought is in LDS (and nothing of it can arrive after the wave has ended)
+__device__ __forceinline__ void quals_landed()
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// qlast (the last call of a read, scores on): while the queues are drained for the last time, the qualities of the wave's
+// reads travel into the place of the rows if quals_ahead() says so; they are at ROWBUF_OFF of the wave's region when
+// the function returns.
 template <int W, bool SCORES, bool ALL, bool DEFER, bool WIDE, int LA0, int LA1>
-__device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL, uint8_t *stg, bool act)
+__device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL, uint8_t *stg, bool act,
+                                                 bool qlast = false)
 {
     constexpr int NL = LA1 - LA0;
     const uint32_t lane = threadIdx.x & 63;
@@ -605,7 +656,7 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
         return (sa_ << bb) | sc_;
     };
     auto bucket_of = [&](int la) { return wide ? (uint32_t)(sig_wide(la) >> a.ix.pshift) : (sig_of(la) >> gbits); };
-    uint32_t qn = 0;
+    uint32_t qn = 0, q_last = 0, q_lastla = 0; // queue fill; position and list bits of the entry pushed last
     uint4 va0, va1, va2, va3, va4, va5, va6, va7; // (eight scalars, not an array: the array went through scratch memory)
     uint32_t *bkx = reinterpret_cast<uint32_t *>(stg + BKX_OFF);
     // the eight loads of list la: lane (8g+j) reads piece j of the row of owner 8*it+g.  The owners' bucket numbers go
@@ -622,10 +673,35 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
         va3 = R_[(uint64_t)b0_.w * 8]; va4 = R_[(uint64_t)b1_.x * 8]; va5 = R_[(uint64_t)b1_.y * 8];                        \
         va6 = R_[(uint64_t)b1_.z * 8]; va7 = R_[(uint64_t)b1_.w * 8];                                                       \
     } while (0)
+    // the last list of the read is decoded, the rows are dead: the qualities of the wave's reads go straight into their place
+    // (LDS-DMA: lane i's 16 bytes land at base + 16 i, no registers) while the queues are drained for the last time.
+    // (inline assembly: the compiler must not count these among its loads -- it would hold every LDS access of the loop
+    // until they have landed; quals_landed() is the wait)
+#define ISSUE_QUALS()                                                                                                                         \
+    do {                                                                                                                                      \
+        const uint8_t *qsrc;                                                                                                                  \
+        uint32_t qbytes;                                                                                                                      \
+        if (quals_ahead(a, s.o0, s.o1, qsrc, qbytes)) {                                                                                       \
+            wave_lds_sync();                                                                                                                  \
+            const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)rowbuf);   \
+            _Pragma("unroll") for (uint32_t i = 0; i < 8; ++i)                                                                                \
+                if (16u * lane + 1024u * i + 16u <= qbytes) {                                                                                 \
+                    const uint8_t *g_ = qsrc + 16u * lane + 1024u * i;                                                                        \
+                    uint32_t keep_;                                                                                                           \
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                                 : "=&s"(keep_) : "v"(g_), "s"(lds0 + 1024u * i) : "memory");                                                 \
+                }                                                                                                                             \
+            const uint32_t tail0 = qbytes & ~15u; /* (what the last whole 16 bytes leave over) */                                             \
+            if (lane < (qbytes & 15u)) rowbuf[tail0 + lane] = qsrc[tail0 + lane];                                                             \
+        }                                                                                                                                     \
+    } while (0)
     ISSUE_ROWS(LA0);
 #pragma unroll 1
     for (int li = 0; li < NL; ++li) { // (a real loop: the drain below must exist once, not NL times)
         const int la = LA0 + li;
+#if RH_PHASE_TIMING
+        const unsigned ph0 = PH_NOW();
+#endif
         // rows -> LDS: piece j of row r at r * 128 + ((j ^ (r & 7)) * 16) (16-byte stores; the swizzle spreads the owners'
         // reads of the same dword of different rows over eight bank groups)
         wave_lds_sync();
@@ -638,6 +714,10 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
             *reinterpret_cast<uint4 *>(d + 6 * 1024) = va6; *reinterpret_cast<uint4 *>(d + 7 * 1024) = va7;
         }
         wave_lds_sync();
+#if RH_PHASE_TIMING
+        unsigned ph1 = PH_NOW();
+        s.tW += ph1 - ph0;
+#endif
         if (li + 1 < NL) ISSUE_ROWS(la + 1); // the next list's rows are in flight while this one is decoded and drained
         // owners: directory of the row, then the entries of their key group
         const bool mine = act && !(s.p_n == PEND_OVF) && !(RH_ABLATE & 8);
@@ -655,7 +735,7 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
             g = r >> 28;
         }
         if (mine) {
-            s.cL++;
+            s.addL(1u);
             const uint32_t h0 = row(0), h1 = row(1);
             if ((h0 & h1) != 0xffffffffu) {
                 // sixteen 4-bit counts: mine, and the sum of those in front of it
@@ -694,42 +774,56 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
                     e_cnt = x - e_base;
                 }
             }
-            if (!wide) s.cC += e_cnt; // (wide: counted when the text confirms the membership)
-            s.cP += e_cnt;
+            if (!wide) s.addC(e_cnt); // (wide: counted when the text confirms the membership)
+            s.addP(e_cnt);
             if (e_cnt > BIG_T) { s.p_n = PEND_OVF; e_cnt = 0; } // a long equal range is walked by a whole wave (match_wave.hip)
             if (RH_ABLATE & 4) e_cnt = 0;
         }
-        while (true) {
-            while (e_j < e_cnt && qn < MQR) {
-                uint32_t pos;
-                bool pass;
-                if (!e_ovf) { // 6 bytes at halfword 4 + 3 * (e_base + e_j) of the row
-                    const uint32_t h = 4 + 3 * (e_base + e_j);
-                    const uint32_t d0 = row(h >> 1), d1 = row((h >> 1) + 1);
-                    const uint32_t key = (h & 1) ? (d0 >> 16) : (d0 & 0xffffu);
-                    pos = (h & 1) ? d1 : ((d0 >> 16) | (d1 << 16));
-                    const uint32_t x = key ^ (r >> (pbits - p16));
-                    pass = wide ? (key == rh_fp16(r)) : (__popc(((x >> 1) | x) & 0x5555u) <= a.seedkmax);
-                } else {
-                    const uint2 e = a.ix.ent[la][e_base + e_j];
-                    pos = e.y;
-                    const uint32_t x = (e.x & pmask) ^ r;
-                    pass = wide ? (e.x == r) : (__popc(((x >> 1) | x) & 0x55555555u) <= a.seedkmax);
-                }
-                // seed popcount filter (match.hpp:386) on the partner symbols the entry carries: more than seedkmax
-                // known mismatches => rejected without touching the text (exact: the full count can only be larger)
-                if (pass) queue_push(q_pos, q_la, qn, pos, la);
-                e_j++;
+        const uint32_t rk = wide ? rh_fp16(r) : (r >> (pbits - p16)); // what the 16 key bits of a row entry are compared with
+        // the entries of the lanes' key groups, one per lane and step, without branches on the way: a survivor of the
+        // partner filter goes to the lane's queue; the same window reached through the next list right after only sets
+        // that list's bit -- the lane's last queue entry is kept in registers, nothing is read back.  A lane that needs
+        // more than MQR queue slots for one strand (repeat-rich loci only) hands its read over: the queues are drained
+        // once, behind the lists, where the registers that hold the rows in flight are free again.
+        while (__any(e_j < e_cnt)) {
+            const bool step = e_j < e_cnt;
+            uint32_t pos, x;
+            if (!e_ovf) { // 6 bytes at halfword 4 + 3 * (e_base + e_j) of the row
+                const uint32_t h = step ? 4 + 3 * (e_base + e_j) : 4u;
+                const uint32_t d0 = row(h >> 1), d1 = row((h >> 1) + 1);
+                const uint32_t key = (h & 1) ? (d0 >> 16) : (d0 & 0xffffu);
+                pos = (h & 1) ? d1 : ((d0 >> 16) | (d1 << 16));
+                x = key ^ rk;
+            } else {
+                const uint2 e = step ? a.ix.ent[la][e_base + e_j] : make_uint2(0u, 0u);
+                pos = e.y;
+                x = wide ? (e.x ^ r) : ((e.x & pmask) ^ r);
             }
-            if (!__any(e_j < e_cnt) && li + 1 < NL) break;
-            // a full queue somewhere, or the end of the lists: verify / score / fold in candidate order
-            for (uint32_t k = 0; k < qn; ++k)
-                process_candidate<W, SCORES, ALL, DEFER>(a, s, sLL, q_pos[k * 64], (uint32_t)q_la[k * 64]);
-            qn = 0;
-            if (s.p_n == PEND_OVF) e_j = e_cnt;
-            if (!__any(e_j < e_cnt)) break;
+            // seed popcount filter (match.hpp:386) on the partner symbols the entry carries: more than seedkmax
+            // known mismatches => rejected without touching the text (exact: the full count can only be larger)
+            bool pass = step && (wide ? (x == 0u) : (__popc(((x >> 1) | x) & 0x55555555u) <= a.seedkmax));
+            const bool merge = pass && qn && pos == q_last;
+            if (pass && !merge && qn == MQR) { s.p_n = PEND_OVF; e_cnt = 0; pass = false; } // (match_wave.hip takes the read)
+            const uint32_t slot = merge ? qn - 1 : qn;
+            const uint32_t lav = (merge ? q_lastla : 0u) | (1u << la);
+            if (pass) { q_pos[slot * 64] = pos; q_la[slot * 64] = (uint8_t)lav; q_last = pos; q_lastla = lav; qn = slot + 1; }
+            e_j += step ? 1u : 0u;
         }
+#if RH_PHASE_TIMING
+        s.tD += PH_NOW() - ph1;
+#endif
     }
+    if (SCORES && qlast) ISSUE_QUALS();
+#undef ISSUE_QUALS
+#if RH_PHASE_TIMING
+    const unsigned ph2 = PH_NOW();
+#endif
+    // verify / score / fold in candidate order
+    for (uint32_t k = 0; k < qn; ++k)
+        process_candidate<W, SCORES, ALL, DEFER>(a, s, sLL, q_pos[k * 64], (uint32_t)q_la[k * 64]);
+#if RH_PHASE_TIMING
+    s.tR += PH_NOW() - ph2;
+#endif
 }
 
 // both strands of one read with bucket rows: every lane of the wave comes along, `act` tells which ones have a read
@@ -737,9 +831,6 @@ template <int W, bool SCORES, bool ALL, bool DEFER, bool WIDE>
 __device__ __forceinline__ void match_read_rows(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL, uint8_t *stg, bool act)
 {
     const uint32_t patl = act ? s.patl : 32u * W;
-    s.nw = (patl + 31) >> 5;
-    s.lastmask = ~0ull << (64 - 2 * (patl - 32 * (s.nw - 1)));
-    s.eps = (float)(a.filter_mult * (double)patl); // RealOptions.hpp:74-77
     s.p_n = s.p_nev = s.p_ev = 0; s.cslot = SLOT_NONE;
     uint64_t rhi = 0, rlo = 0;
     if (act) seed_halves<W>(s.O, a.l, s.shi, s.slo, rhi, rlo);
@@ -753,7 +844,6 @@ __device__ __forceinline__ void match_read_rows(const MatchArgs &a, LaneState<W,
             s.shi = rhi; s.slo = rlo;
         }
         s.inv = inv;
-        s.so = inv ? (patl - a.l) : 0u; // RestMatch::getMatchOffset, RestMatch.hpp:84-89
         s.cpos = 0xffffffffu; s.ck = 0; s.cfrag = 0; s.cscore = 1.0f; s.cok = false;
         s.crpos = 0xffffffffu; s.ckk = 0;
         const bool go = act && !(s.p_n == PEND_OVF);
@@ -764,7 +854,7 @@ __device__ __forceinline__ void match_read_rows(const MatchArgs &a, LaneState<W,
             const unsigned st = (unsigned)(s.info >> ST_SHIFT), er = (unsigned)(s.info >> ER_SHIFT) & 15;
             match_lists_rows<W, SCORES, ALL, DEFER, WIDE, 1, 6>(a, s, sLL, stg, go && !(st == (unsigned)(inv ? ST_REVERSE : ST_STRAIGHT) && er == 0));
         } else {
-            match_lists_rows<W, SCORES, ALL, DEFER, WIDE, 0, 6>(a, s, sLL, stg, go);
+            match_lists_rows<W, SCORES, ALL, DEFER, WIDE, 0, 6>(a, s, sLL, stg, go, inv != 0);
         }
     }
 }
@@ -776,9 +866,6 @@ __device__ __forceinline__ void match_read(const MatchArgs &a, LaneState<W, SCOR
                                            uint8_t *q_la)
 {
     const uint32_t patl = s.patl;
-    s.nw = (patl + 31) >> 5;
-    s.lastmask = ~0ull << (64 - 2 * (patl - 32 * (s.nw - 1)));
-    s.eps = (float)(a.filter_mult * (double)patl); // RealOptions.hpp:74-77
     s.p_n = s.p_nev = s.p_ev = 0; s.cslot = SLOT_NONE;
     uint64_t rhi, rlo;
     seed_halves<W>(s.O, a.l, s.shi, s.slo, rhi, rlo);
@@ -792,7 +879,6 @@ __device__ __forceinline__ void match_read(const MatchArgs &a, LaneState<W, SCOR
             s.shi = rhi; s.slo = rlo;
         }
         s.inv = inv;
-        s.so = inv ? (patl - a.l) : 0u; // RestMatch::getMatchOffset, RestMatch.hpp:84-89
         s.cpos = 0xffffffffu; s.ck = 0; s.cfrag = 0; s.cscore = 1.0f; s.cok = false;
         s.crpos = 0xffffffffu; s.ckk = 0;
         if (!ALL && !SCORES) {
@@ -821,20 +907,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
 {
     constexpr bool FINE = TK != 0;
     constexpr bool DEFER = SCORES || ALL;
+    const unsigned ph_start = PH_NOW();
     __shared__ double sLL[SCORES ? RH_LL_SLOTS : 1];
     __shared__ __attribute__((aligned(16))) uint8_t smem[4 * stg_bytes(W, TK)];
-    if (SCORES) {
-        for (int i = threadIdx.x; i < 1024; i += 256) sLL[i] = a.LL[i];
-        if (threadIdx.x == 0) sLL[RH_LL_ZERO] = 0.0;
-        __syncthreads();
-    }
+    double ll0 = 0, ll1 = 0, ll2 = 0, ll3 = 0; // the score table: requested here, in LDS when the front is through
+    if (SCORES) { ll0 = a.LL[threadIdx.x]; ll1 = a.LL[threadIdx.x + 256]; ll2 = a.LL[threadIdx.x + 512]; ll3 = a.LL[threadIdx.x + 768]; }
     const uint32_t lane = threadIdx.x & 63;
     uint8_t *stg = smem + (threadIdx.x >> 6) * stg_bytes(W, TK);
     uint32_t *q_pos = reinterpret_cast<uint32_t *>(stg) + lane;
     uint8_t *q_la = stg + MQ * 64 * 4 + lane;
     LaneState<W, SCORES, ALL> s;
-    s.cL = s.cP = s.cC = s.cS = s.cH = s.cV = 0;
-    s.info = 0; s.iscore = 0.f; s.o0 = 0;
+    s.cA = s.cB = 0;
+#if RH_PHASE_TIMING
+    s.tW = s.tD = s.tR = 0;
+    unsigned tQ = 0, tS = 0;
+#endif
+    s.info = 0; s.iscore = 0.f; s.o0 = s.o1 = 0;
     unsigned cR = 0;
     const uint64_t n = a.b.n_reads;
 
@@ -872,6 +960,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
         }
     }
     if (toolong) atomicOr(a.err_flags, 1u); // the host turns this into REAL_HIP_E_INVALID
+    if (SCORES) {
+        sLL[threadIdx.x] = ll0; sLL[threadIdx.x + 256] = ll1; sLL[threadIdx.x + 512] = ll2; sLL[threadIdx.x + 768] = ll3;
+        if (threadIdx.x == 0) sLL[RH_LL_ZERO] = 0.0;
+        __syncthreads();
+    }
     wave_lds_sync();
     // ---- match
     s.r = r; s.patl = patl; s.p_n = 0; s.nhit = 0;
@@ -880,6 +973,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
         if (SCORES) s.iscore = a.score[r];
     }
     if (!ALL && a.b.fresh) s.iscore = -3.402823466e+38f; // uniqueinfo(numpat): NoMatch (info 0), score -FLT_MAX (UniqueMatchInfo.hpp:191)
+    const unsigned ph_front = PH_NOW();
+    s.o0 = o0; s.o1 = o1;
     if (TK >= 3) // bucket rows: lookups by lane groups, the whole wave comes along
         match_read_rows<W, SCORES, ALL, DEFER, TK == 4>(a, s, sLL, stg, elig);
     else if (elig)
@@ -889,19 +984,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
         // nothing of this read has been delivered: the wave-cooperative matcher does it all and counts it
         const unsigned long long slot = wave_append_slot(a.ovf_count);
         a.ovf_list[slot] = (uint32_t)r;
-        s.cL = s.cP = s.cC = s.cS = s.cH = s.cV = 0;
+        s.cA = s.cB = 0;
     }
     // ---- qualities: global -> LDS; score the parked hits and deliver them
+    const uint8_t *qsrc_ = nullptr;
+    uint32_t qbytes_ = 0;
+    const bool q_ahead = TK >= 3 && SCORES && quals_ahead(a, o0, o1, qsrc_, qbytes_); // (then match_lists_rows has started them)
+    if (q_ahead) quals_landed();
     if (DEFER) {
         for (uint32_t g = 0; g < 64; g += GL) {
             const uint64_t gb = __shfl(o0, (int)g), ge = __shfl(o1, (int)(g + GL - 1));
             const bool mine = lane >= g && lane < g + GL && elig && !ovf && s.p_n;
             if (!__any(mine)) continue;
             uint32_t l0 = 0;
-            wave_lds_sync();
-            if (SCORES && a.b.qual) l0 = stage_wave(stg, a.b.qual + gb, ge - gb, lane); // (fits: the bases of this group did)
-            wave_lds_sync();
+#if RH_PHASE_TIMING
+            const unsigned pq0 = PH_NOW();
+#endif
+            if (q_ahead) {
+                wave_lds_sync();
+                l0 = ROWBUF_OFF;
+            } else {
+                wave_lds_sync();
+                if (SCORES && a.b.qual) l0 = stage_wave(stg, a.b.qual + gb, ge - gb, lane); // (fits: the bases of this group did)
+                wave_lds_sync();
+            }
+#if RH_PHASE_TIMING
+            const unsigned pq1 = PH_NOW();
+            tQ += pq1 - pq0;
+#endif
             if (mine) flush_pending<W, SCORES, ALL>(a, s, sLL, LdsRow{stg, l0 + (uint32_t)(o0 - gb)});
+#if RH_PHASE_TIMING
+            tS += PH_NOW() - pq1;
+#endif
         }
     }
     if (elig && !ovf) {
@@ -917,9 +1031,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
     if (ALL && r < n) a.hit_cnt[r] = (elig && !ovf) ? s.nhit : 0u; // (a handed-over read: the wave matcher writes it)
 
     // work counters: wave reduction, one atomic per wave and counter
-    unsigned c[7] = {cR, s.cL, s.cP, s.cC, s.cS, s.cH, s.cV};
+#if RH_PHASE_TIMING
+    const bool l0_ = (threadIdx.x & 63) == 0;
+    unsigned c[8] = {cR, l0_ ? ph_front - ph_start : 0u, l0_ ? s.tW : 0u, l0_ ? s.tD : 0u, l0_ ? s.tR : 0u, l0_ ? tQ : 0u, l0_ ? tS : 0u, l0_ ? PH_NOW() - ph_start : 0u};
+    constexpr int NC = 8;
+#else
+    unsigned c[7] = {cR, s.cA & 15u, s.cB & 2047u, (s.cB >> 11) & 2047u, s.cA >> 16, s.cB >> 22, (s.cA >> 4) & 4095u};
+    constexpr int NC = 7;
+    (void)ph_start; (void)ph_front;
+#endif
 #pragma unroll
-    for (int k = 0; k < 7; ++k) {
+    for (int k = 0; k < NC; ++k) {
         unsigned v = c[k];
         for (int d = 32; d; d >>= 1) v += __shfl_xor((int)v, d);
         if ((threadIdx.x & 63) == 0 && v)
