@@ -187,28 +187,52 @@ __device__ __forceinline__ void queue_push(uint32_t *q_pos, uint8_t *q_la, uint3
     else { q_pos[qn * 64] = pos; q_la[qn * 64] = (uint8_t)(1u << la); qn++; }
 }
 
+// The text a candidate needs: the two (three) words of its seed window and the words of text[pos, pos + patl).  They are
+// requested together, before anything is decided -- one round trip per candidate instead of two (a queued candidate has
+// passed the partner filter: it nearly always gets as far as the Hamming distance) -- and the drain of the bucket-row
+// matcher requests those of the next candidate before it works on this one.
+template <int W>
+struct CandText {
+    U64x2 tt;
+    uint64_t t2;
+    uint64_t t[W + 2];
+};
+template <int W, bool SCORES, bool ALL>
+__device__ __forceinline__ void cand_load(const MatchArgs &a, const LaneState<W, SCORES, ALL> &s, uint32_t rpos, CandText<W> &c)
+{
+    const uint64_t *__restrict__ T = a.t.text;
+    const uint64_t wi0 = rpos >> 5;
+    c.tt = load2(T + wi0); // the seed window (2*l bits at bit offset 2*rpos) spans two words, three when l > 32
+    c.t2 = (a.l > 32) ? T[wi0 + 2] : 0ull;
+    const uint32_t so = s.so(a.l), nw = s.nw();
+    const uint64_t wi = (rpos - so) >> 5;
+#pragma unroll
+    for (int j = 0; j <= W; j += 2) { // 16-byte requests, all in flight together
+        U64x2 p2 = {0ull, 0ull};
+        if (rpos >= so && (uint32_t)j <= nw) p2 = load2(T + wi + j);
+        c.t[j] = p2.a; c.t[j + 1] = p2.b;
+    }
+}
+
 // lmask = the lists (bit la) through which this window was reached one right after the other: the window is looked at
 // once, its update() events are delivered list by list
 template <int W, bool SCORES, bool ALL, bool DEFER>
-__device__ __forceinline__ void process_candidate(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL,
-                                                  uint32_t rpos, uint32_t lmask)
+__device__ __forceinline__ void process_loaded(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL,
+                                               uint32_t rpos, uint32_t lmask, const CandText<W> &c)
 {
     if (s.p_n == PEND_OVF) return; // handed over
     if (RH_ABLATE & 2) return;
-    const uint64_t *__restrict__ T = a.t.text;
     const uint32_t bb = a.b_bits;
     const uint64_t mb = (bb >= 64) ? ~0ull : ((1ull << bb) - 1);
+    const uint32_t so = s.so(a.l);
+    const uint32_t nw = s.nw();
     // seed window of the genome at rpos, as the two halves (m0|m1), (m2|m3); per-segment mismatch
     // counts are a function of (strand, rpos) only and are memoised: the true locus is reached
     // through up to six lists in a row
     if (rpos != s.crpos) {
-        // the seed window (2*l bits at bit offset 2*rpos) spans two words, three when l > 32
-        const uint64_t wi0 = rpos >> 5;
-        const U64x2 tt = load2(T + wi0);
-        const uint64_t t2 = (a.l > 32) ? T[wi0 + 2] : 0ull;
         const unsigned sh0 = 2u * (rpos & 31);
-        const uint64_t xhi = extract_bits(tt.a, tt.b, t2, sh0, a.l) ^ s.shi;
-        const uint64_t xlo = extract_bits(tt.a, tt.b, t2, sh0 + a.l, a.l) ^ s.slo;
+        const uint64_t xhi = extract_bits(c.tt.a, c.tt.b, c.t2, sh0, a.l) ^ s.shi;
+        const uint64_t xlo = extract_bits(c.tt.a, c.tt.b, c.t2, sh0 + a.l, a.l) ^ s.slo;
         const uint64_t dhi = ((xhi >> 1) | xhi) & M55, dlo = ((xlo >> 1) | xlo) & M55;
         s.ckk = __popcll(dhi >> bb) | (__popcll(dhi & mb) << 8) | (__popcll(dlo >> bb) << 16) | (__popcll(dlo & mb) << 24);
         s.crpos = rpos;
@@ -225,7 +249,6 @@ __device__ __forceinline__ void process_candidate(const MatchArgs &a, LaneState<
     const unsigned seedk = k0 + k1 + k2 + k3; // = diffcountpair(s_b, list_b[p->ptr].sign), match.hpp:386
     if (seedk > a.seedkmax) return;
     s.addS(nm);
-    const uint32_t so = s.so(a.l);
     if (rpos < so) return; // match.hpp:393
     const uint32_t pos = rpos - so;
     bool reg = false; // a location verified here for the first time
@@ -238,23 +261,14 @@ __device__ __forceinline__ void process_candidate(const MatchArgs &a, LaneState<
         if (a.t.has_wild && !wild_free(a.t.wild, pos, s.patl)) return;
         // Hamming distance of the whole oriented read against text[pos, pos+patl)
         // = seedk + RestMatch::computeDistance (RestMatch.hpp:39-81)
-        const uint64_t wi = pos >> 5;
         const unsigned sh = 2u * (pos & 31);
         uint64_t tw[W];
         unsigned total = 0;
-        const uint32_t nw = s.nw();
         const uint64_t lastmask = s.lastmask();
         {
-            uint64_t t[W + 2];
-#pragma unroll
-            for (int j = 0; j <= W; j += 2) { // 16-byte requests, all in flight together
-                U64x2 p2 = {0ull, 0ull};
-                if ((uint32_t)j <= nw) p2 = load2(T + wi + j);
-                t[j] = p2.a; t[j + 1] = p2.b;
-            }
 #pragma unroll
             for (int j = 0; j < W; ++j) {
-                uint64_t al = sh ? ((t[j] << sh) | (t[j + 1] >> (64 - sh))) : t[j];
+                uint64_t al = sh ? ((c.t[j] << sh) | (c.t[j + 1] >> (64 - sh))) : c.t[j];
                 tw[j] = al;
                 uint64_t x = al ^ s.O[j];
                 uint64_t d = ((x >> 1) | x) & M55;
@@ -301,6 +315,16 @@ __device__ __forceinline__ void process_candidate(const MatchArgs &a, LaneState<
     if (s.p_nev + ne > PEND_EV) { s.p_n = PEND_OVF; return; }
     if (s.cslot) s.p_ev |= ((ne >= 32 ? 0xffffffffu : ((1u << ne) - 1u)) << s.p_nev);
     s.p_nev += ne;
+}
+
+template <int W, bool SCORES, bool ALL, bool DEFER>
+__device__ __forceinline__ void process_candidate(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL,
+                                                  uint32_t rpos, uint32_t lmask)
+{
+    if (s.p_n == PEND_OVF) return; // handed over
+    CandText<W> c;
+    cand_load<W, SCORES, ALL>(a, s, rpos, c);
+    process_loaded<W, SCORES, ALL, DEFER>(a, s, sLL, rpos, lmask, c);
 }
 
 // Scan of the buckets of lists [LA0, LA1) of one strand; pushes the entries that survive the key
@@ -818,9 +842,20 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
 #if RH_PHASE_TIMING
     const unsigned ph2 = PH_NOW();
 #endif
-    // verify / score / fold in candidate order
-    for (uint32_t k = 0; k < qn; ++k)
-        process_candidate<W, SCORES, ALL, DEFER>(a, s, sLL, q_pos[k * 64], (uint32_t)q_la[k * 64]);
+    // verify / score / fold in candidate order; the text of the next candidate is on its way while this one is looked at
+    if (s.p_n == PEND_OVF) qn = 0;
+    {
+        CandText<W> c0;
+        uint32_t rp0 = qn ? q_pos[0] : 0u;
+        if (qn) cand_load<W, SCORES, ALL>(a, s, rp0, c0);
+        for (uint32_t k = 0; k < qn; ++k) {
+            CandText<W> c1;
+            uint32_t rp1 = 0;
+            if (k + 1 < qn) { rp1 = q_pos[(k + 1) * 64]; cand_load<W, SCORES, ALL>(a, s, rp1, c1); }
+            process_loaded<W, SCORES, ALL, DEFER>(a, s, sLL, rp0, (uint32_t)q_la[k * 64], c0);
+            c0 = c1; rp0 = rp1;
+        }
+    }
 #if RH_PHASE_TIMING
     s.tR += PH_NOW() - ph2;
 #endif

@@ -292,8 +292,10 @@ static int set_frag(real_hip_ctx *ctx, uint32_t fileid, uint64_t n, const uint64
 
 static int alloc_text(real_hip_ctx *ctx, uint64_t n)
 {
-    // padded: kernels read one word past a window / write whole 64-symbol groups
-    size_t tw = (size_t)((n + 63) / 64) * 2 + 4, ww = (size_t)((n + 63) / 64) + 4;
+    // padded: kernels write whole 64-symbol groups, and the matcher requests the words of text[pos, pos + patl) of a
+    // candidate before it has checked that the read ends inside the text (cand_load: up to RH_MAXW + 2 words from the
+    // last window start on)
+    size_t tw = (size_t)((n + 63) / 64) * 2 + RH_MAXW + 6, ww = (size_t)((n + 63) / 64) + 4;
     int rc = rh_reserve(ctx, ctx->text, tw * 8);
     if (rc) return rc;
     if ((rc = rh_reserve(ctx, ctx->wild, ww * 8))) return rc;
