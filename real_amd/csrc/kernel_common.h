@@ -97,6 +97,20 @@ __device__ __forceinline__ void fold_update(bool inv, unsigned fileid, uint32_t 
     }
 }
 
+// sum of v over the 64 lanes of the wave, the same value in every lane.  Six adds on the data-parallel-primitive paths of
+// the vector ALU (a scan inside the rows of 16, then the row totals are handed on) -- nothing goes through the LDS
+// crossbar, where a butterfly of __shfl_xor queues behind the LDS traffic of the other waves of the CU.
+__device__ __forceinline__ unsigned wave_sum(unsigned v)
+{
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); // row_shr:1
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true); // row_shr:2
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true); // row_shr:4
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true); // row_shr:8: lane 15 of a row = its total
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true); // row_bcast:15 into rows 1 and 3
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true); // row_bcast:31 into rows 2 and 3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // wave-aggregated append: the lanes of the wave that are active here take
 // consecutive slots behind one atomic (ballot + prefix popcount).
 __device__ __forceinline__ unsigned long long wave_append_slot(unsigned long long *counter)

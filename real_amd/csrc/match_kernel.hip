@@ -30,6 +30,7 @@
 // the HBM lines it moves (20.7 per read with digest tables, 95 % of the sustainable line rate), not by
 // arithmetic (no MFMA: XOR/popcount and a short FP64 add chain).
 #include "match_common.h"
+#include <cstdlib>
 
 // RH_ABLATE (experimental builds only, make variant): bit 0 no scoring, bit 1 no verification of queued candidates,
 // bit 2 no entries examined, bit 3 bucket rows fetched but not decoded -- results are wrong, the time tells what a stage costs
@@ -643,7 +644,8 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
                                                  bool qlast = false)
 {
     constexpr int NL = LA1 - LA0;
-    const uint32_t lane = threadIdx.x & 63;
+    uint32_t lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane)); // (not to be carried across the tile loop of the kernel)
     // the wave's LDS region in this mode: MQR x 64 queued positions, MQR x 64 lists, 64 rows of 128 bytes
     uint32_t *q_pos = reinterpret_cast<uint32_t *>(stg) + lane;
     uint8_t *q_la = stg + MQR * 64 * 4 + lane;
@@ -938,19 +940,44 @@ __device__ __forceinline__ void match_read(const MatchArgs &a, LaneState<W, SCOR
 // TK = kind of the bucket tables: 0 bucket starts, 1 directory entries (digests / fingerprints), 3 bucket rows,
 // 4 bucket rows of signatures wider than 32 bits
 template <int W, bool SCORES, bool ALL, int TK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 : 2))) void match_kernel(MatchArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 : 2))) void match_kernel(MatchArgs a_)
 {
     constexpr bool FINE = TK != 0;
     constexpr bool DEFER = SCORES || ALL;
-    const unsigned ph_start = PH_NOW();
     __shared__ double sLL[SCORES ? RH_LL_SLOTS : 1];
     __shared__ __attribute__((aligned(16))) uint8_t smem[4 * stg_bytes(W, TK)];
-    double ll0 = 0, ll1 = 0, ll2 = 0, ll3 = 0; // the score table: requested here, in LDS when the front is through
-    if (SCORES) { ll0 = a.LL[threadIdx.x]; ll1 = a.LL[threadIdx.x + 256]; ll2 = a.LL[threadIdx.x + 512]; ll3 = a.LL[threadIdx.x + 768]; }
-    const uint32_t lane = threadIdx.x & 63;
-    uint8_t *stg = smem + (threadIdx.x >> 6) * stg_bytes(W, TK);
+    if (SCORES) { // the score table, once per workgroup
+        for (int i = threadIdx.x; i < 1024; i += 256) sLL[i] = a_.LL[i];
+        if (threadIdx.x == 0) sLL[RH_LL_ZERO] = 0.0;
+        __syncthreads();
+    }
+    // The grid is as many workgroups as the device holds at a time.  Every wave works through tiles of 64 reads on its own (no
+    // workgroup barrier below this line) and takes its next tile from a counter when it is done -- the number of the tile
+    // after this one is requested at the start of the tile, it is there at its end.  With one workgroup per 256 reads the
+    // wave slots of a workgroup stay empty until its slowest wave has finished and the next workgroup has been
+    // dispatched (16 % of the slot time on the C2 workload); with a fixed share of tiles per wave the grid waits for the
+    // slowest wave at the end (11 %).
+    const uint64_t n_tiles = (a_.b.n_reads + 63) / 64;
+    uint32_t next_raw = 0; // (lane 0 holds the answer of the counter)
+    if ((threadIdx.x & 63) == 0) next_raw = atomicAdd(a_.tile_ctr, 1u);
+    while (true) {
+    const uint64_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)next_raw);
+    if (tile >= n_tiles) break;
+    if ((threadIdx.x & 63) == 0) next_raw = atomicAdd(a_.tile_ctr, 1u);
+    // (what depends on the lane number only is derived again for every tile: carried across the loop it would take
+    // registers of all the rest)
+    uint32_t tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    // ... and the kernel's arguments are read from the kernel argument segment where they are used (scalar loads that hit
+    // the scalar cache), tile by tile: all of them hoisted in front of the loop do not fit the scalar registers
+    const __attribute__((address_space(4))) MatchArgs *pa = (const __attribute__((address_space(4))) MatchArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(pa));
+    const MatchArgs &a = *(const MatchArgs *)pa;
+    const uint32_t lane = tid & 63;
+    uint8_t *stg = smem + (tid >> 6) * stg_bytes(W, TK);
     uint32_t *q_pos = reinterpret_cast<uint32_t *>(stg) + lane;
     uint8_t *q_la = stg + MQ * 64 * 4 + lane;
+    const unsigned ph_start = PH_NOW();
     LaneState<W, SCORES, ALL> s;
     s.cA = s.cB = 0;
 #if RH_PHASE_TIMING
@@ -961,7 +988,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
     unsigned cR = 0;
     const uint64_t n = a.b.n_reads;
 
-    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t r = tile * 64 + lane;
     const uint64_t rc = r < n ? r : n; // lanes behind the batch: an empty range at its end
     const uint64_t o0 = a.b.off ? a.b.off[rc] : rc * (uint64_t)a.b.upatl;
     const uint64_t o1 = r < n ? (a.b.off ? a.b.off[r + 1] : o0 + a.b.upatl) : o0;
@@ -995,11 +1022,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
         }
     }
     if (toolong) atomicOr(a.err_flags, 1u); // the host turns this into REAL_HIP_E_INVALID
-    if (SCORES) {
-        sLL[threadIdx.x] = ll0; sLL[threadIdx.x + 256] = ll1; sLL[threadIdx.x + 512] = ll2; sLL[threadIdx.x + 768] = ll3;
-        if (threadIdx.x == 0) sLL[RH_LL_ZERO] = 0.0;
-        __syncthreads();
-    }
     wave_lds_sync();
     // ---- match
     s.r = r; s.patl = patl; s.p_n = 0; s.nhit = 0;
@@ -1067,7 +1089,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
 
     // work counters: wave reduction, one atomic per wave and counter
 #if RH_PHASE_TIMING
-    const bool l0_ = (threadIdx.x & 63) == 0;
+    const bool l0_ = lane == 0;
     unsigned c[8] = {cR, l0_ ? ph_front - ph_start : 0u, l0_ ? s.tW : 0u, l0_ ? s.tD : 0u, l0_ ? s.tR : 0u, l0_ ? tQ : 0u, l0_ ? tS : 0u, l0_ ? PH_NOW() - ph_start : 0u};
     constexpr int NC = 8;
 #else
@@ -1077,11 +1099,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
 #endif
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
-        unsigned v = c[k];
-        for (int d = 32; d; d >>= 1) v += __shfl_xor((int)v, d);
-        if ((threadIdx.x & 63) == 0 && v)
-            atomicAdd(a.counters + (size_t)((blockIdx.x * 4u + (threadIdx.x >> 6)) & (RH_CSTRIPES - 1)) * 16 + k, (unsigned long long)v);
+        const unsigned v = wave_sum(c[k]);
+        if (lane == 0 && v)
+            atomicAdd(a.counters + (size_t)(tile & (RH_CSTRIPES - 1)) * 16 + k, (unsigned long long)v);
     }
+    } // tiles
 }
 
 // ---------------------------------------------------------------------------
@@ -1091,17 +1113,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
 #ifndef RH_W
 #error "compile with -DRH_W=<1..10>"
 #endif
+// as many workgroups as the device holds of this instance at a time (its registers and LDS decide), at most one per 256 reads
+static void launch_resident(void (*kernel)(MatchArgs), real_hip_ctx *ctx, const MatchArgs &a)
+{
+    int per_cu = 0, dev = 0, n_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 1) n_cu = 256;
+    static const bool full_grid = getenv("REAL_HIP_FULL_GRID") != nullptr; // (experiments: one workgroup per 256 reads, every wave does one tile)
+    const uint64_t want = (a.b.n_reads + 255) / 256, have = full_grid ? want : (uint64_t)per_cu * (uint64_t)n_cu;
+    dim3 grid((unsigned)(want < have ? want : have)), block(256);
+    hipLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, a);
+}
+
 template <int W, int TK>
 static void launch_match_wt(real_hip_ctx *ctx, const MatchArgs &a, bool all)
 {
-    dim3 grid((unsigned)((a.b.n_reads + 255) / 256)), block(256);
     const bool sc = ctx->prm.scores != 0;
     if (all) {
-        if (sc) hipLaunchKernelGGL((match_kernel<W, true, true, TK>), grid, block, 0, ctx->stream, a);
-        else    hipLaunchKernelGGL((match_kernel<W, false, true, TK>), grid, block, 0, ctx->stream, a);
+        if (sc) launch_resident(match_kernel<W, true, true, TK>, ctx, a);
+        else    launch_resident(match_kernel<W, false, true, TK>, ctx, a);
     } else {
-        if (sc) hipLaunchKernelGGL((match_kernel<W, true, false, TK>), grid, block, 0, ctx->stream, a);
-        else    hipLaunchKernelGGL((match_kernel<W, false, false, TK>), grid, block, 0, ctx->stream, a);
+        if (sc) launch_resident(match_kernel<W, true, false, TK>, ctx, a);
+        else    launch_resident(match_kernel<W, false, false, TK>, ctx, a);
     }
 }
 #define RH_CAT2(a, b) a##b

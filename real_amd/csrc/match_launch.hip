@@ -30,11 +30,12 @@ int rh_launch_match(real_hip_ctx *ctx, const MatchArgs &args, bool all, int stat
     }
     // hand-over list of the reads the matcher leaves to the wave-cooperative kernel; [0] its length, [1] error flags
     if ((rc = rh_reserve(ctx, ctx->ovf_list, a.b.n_reads * 4))) return rc;
-    if ((rc = rh_reserve(ctx, ctx->ovf_count, 16))) return rc;
+    if ((rc = rh_reserve(ctx, ctx->ovf_count, 32))) return rc;
     a.ovf_list = (uint32_t *)ctx->ovf_list.p;
     a.ovf_count = (unsigned long long *)ctx->ovf_count.p;
     a.err_flags = (uint32_t *)((unsigned long long *)ctx->ovf_count.p + 1);
-    RH_HIP(ctx, hipMemsetAsync(ctx->ovf_count.p, 0, 16, ctx->stream));
+    a.tile_ctr = (uint32_t *)((unsigned long long *)ctx->ovf_count.p + 2);
+    RH_HIP(ctx, hipMemsetAsync(ctx->ovf_count.p, 0, 32, ctx->stream));
     rh_time_begin(ctx, ctx->stream, all ? REAL_HIP_K_MATCH_ALL : REAL_HIP_K_MATCH_UNIQUE);
     launch[a.b.W - 1](ctx, a, all);
     rh_time_end(ctx, ctx->stream);

@@ -416,8 +416,7 @@ __global__ __launch_bounds__(256) void match_wave_kernel(MatchArgs a)
     unsigned c[8] = {cR, cL, cP, cC, cS, cH, cV, cR};
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        unsigned v = c[k];
-        for (int d = 32; d; d >>= 1) v += __shfl_xor((int)v, d);
+        const unsigned v = wave_sum(c[k]);
         if (lane == 0 && v)
             atomicAdd(a.counters + (size_t)((blockIdx.x * 4u + (threadIdx.x >> 6)) & (RH_CSTRIPES - 1)) * 16 + k, (unsigned long long)v);
     }

@@ -108,6 +108,7 @@ struct MatchArgs {
     uint32_t *ovf_list;
     unsigned long long *ovf_count;
     uint32_t *err_flags;   // bit 0: a read longer than the declared bound / offsets not monotone (nothing was staged for it)
+    uint32_t *tile_ctr;    // the next tile of 64 reads to be handed out (match_kernel: the waves of a resident grid take tiles as they get done)
     double   filter_mult;
     uint32_t l, q, b_bits, seedkmax, totalkmax;
 };
