@@ -621,14 +621,20 @@ __device__ __forceinline__ void wave_lds_sync()
 // at a multiple of 16 and fit the place of the rows, has them brought there by LDS-DMA while it drains its queues for the
 // last time.  Decided from the offsets of the reads alone, at both places that need to know (nothing is carried along:
 // the scalar registers are all in use).
-__device__ __forceinline__ bool quals_ahead(const MatchArgs &a, uint64_t o0, uint64_t o1, const uint8_t *&src, uint32_t &nbytes)
+__device__ __forceinline__ bool quals_ahead(const MatchArgs &a, uint64_t o0, uint64_t o1, uint32_t cap, const uint8_t *&src, uint32_t &nbytes, uint32_t &late)
 {
     if (!a.b.qual || a.b.gl < 64) return false;
     const uint64_t gb = __shfl(o0, 0), ge = __shfl(o1, 63);
     src = a.b.qual + gb;
     nbytes = (uint32_t)(ge - gb);
-    return ge >= gb && ge - gb <= 64u * 128u && ((uintptr_t)src & 15u) == 0;
+    // up to 8 KiB: everything into the place of the rows.  More (reads of 129 .. 170 bases): the bytes lie from STG_PAD on,
+    // as stage_wave() puts them; what comes to lie under the queues -- the first `late` bytes -- follows when the queues
+    // have been drained
+    late = nbytes <= 64u * 128u ? 0u : ROWBUF_OFF - STG_PAD;
+    return ge >= gb && ge - gb <= cap && ((uintptr_t)src & 15u) == 0;
 }
+// where they lie in the wave's region
+__device__ __forceinline__ uint32_t quals_at(uint32_t late) { return late ? STG_PAD : ROWBUF_OFF; }
 
 // every byte that quals_ahead()'s LDS-DMA brought is in LDS (and nothing of it can arrive after the wave has ended)
 __device__ __forceinline__ void quals_landed()
@@ -637,8 +643,8 @@ __device__ __forceinline__ void quals_landed()
 }
 
 // qlast (the last call of a read, scores on): while the queues are drained for the last time, the qualities of the wave's
-// reads travel into the place of the rows if quals_ahead() says so; they are at ROWBUF_OFF of the wave's region when
-// the function returns.
+// reads travel into the wave's region if quals_ahead() says so (at quals_at() when the function returns and
+// quals_landed() has waited).
 template <int W, bool SCORES, bool ALL, bool DEFER, bool WIDE, int LA0, int LA1>
 __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL, uint8_t *stg, bool act,
                                                  bool qlast = false)
@@ -703,22 +709,34 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
     // (LDS-DMA: lane i's 16 bytes land at base + 16 i, no registers) while the queues are drained for the last time.
     // (inline assembly: the compiler must not count these among its loads -- it would hold every LDS access of the loop
     // until they have landed; quals_landed() is the wait)
+#define QUAL_DMA(SRC_OFF, LDS_ADDR, NBYTES, NCHUNK)                                                                                           \
+    _Pragma("unroll") for (uint32_t i = 0; i < (NCHUNK); ++i)                                                                                 \
+        if (16u * lane + 1024u * i + 16u <= (NBYTES)) {                                                                                       \
+            const uint8_t *g_ = qsrc + (SRC_OFF) + 16u * lane + 1024u * i;                                                                    \
+            uint32_t keep_;                                                                                                                   \
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"         \
+                         : "=&s"(keep_) : "v"(g_), "s"((LDS_ADDR) + 1024u * i) : "memory");                                                   \
+        }
 #define ISSUE_QUALS()                                                                                                                         \
     do {                                                                                                                                      \
         const uint8_t *qsrc;                                                                                                                  \
-        uint32_t qbytes;                                                                                                                      \
-        if (quals_ahead(a, s.o0, s.o1, qsrc, qbytes)) {                                                                                       \
+        uint32_t qbytes, qlate;                                                                                                               \
+        if (quals_ahead(a, s.o0, s.o1, stg_bytes(W, 3) - STG_PAD - 32u, qsrc, qbytes, qlate)) {                                               \
             wave_lds_sync();                                                                                                                  \
             const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)rowbuf);   \
-            _Pragma("unroll") for (uint32_t i = 0; i < 8; ++i)                                                                                \
-                if (16u * lane + 1024u * i + 16u <= qbytes) {                                                                                 \
-                    const uint8_t *g_ = qsrc + 16u * lane + 1024u * i;                                                                        \
-                    uint32_t keep_;                                                                                                           \
-                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
-                                 : "=&s"(keep_) : "v"(g_), "s"(lds0 + 1024u * i) : "memory");                                                 \
-                }                                                                                                                             \
+            QUAL_DMA(qlate, lds0, qbytes - qlate, 9u)                                                                                         \
             const uint32_t tail0 = qbytes & ~15u; /* (what the last whole 16 bytes leave over) */                                             \
-            if (lane < (qbytes & 15u)) rowbuf[tail0 + lane] = qsrc[tail0 + lane];                                                             \
+            if (lane < (qbytes & 15u)) rowbuf[tail0 - qlate + lane] = qsrc[tail0 + lane];                                                     \
+        }                                                                                                                                     \
+    } while (0)
+#define ISSUE_QUALS_LATE() /* the queues are drained: what lies in their place */                                                             \
+    do {                                                                                                                                      \
+        const uint8_t *qsrc;                                                                                                                  \
+        uint32_t qbytes, qlate;                                                                                                               \
+        if (quals_ahead(a, s.o0, s.o1, stg_bytes(W, 3) - STG_PAD - 32u, qsrc, qbytes, qlate) && qlate) {                                      \
+            wave_lds_sync();                                                                                                                  \
+            const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)stg);      \
+            QUAL_DMA(0u, lds0 + STG_PAD, qlate, 3u)                                                                                           \
         }                                                                                                                                     \
     } while (0)
     ISSUE_ROWS(LA0);
@@ -840,7 +858,6 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
 #endif
     }
     if (SCORES && qlast) ISSUE_QUALS();
-#undef ISSUE_QUALS
 #if RH_PHASE_TIMING
     const unsigned ph2 = PH_NOW();
 #endif
@@ -861,6 +878,10 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
 #if RH_PHASE_TIMING
     s.tR += PH_NOW() - ph2;
 #endif
+    if (SCORES && qlast) ISSUE_QUALS_LATE();
+#undef ISSUE_QUALS
+#undef ISSUE_QUALS_LATE
+#undef QUAL_DMA
 }
 
 // both strands of one read with bucket rows: every lane of the wave comes along, `act` tells which ones have a read
@@ -1045,8 +1066,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
     }
     // ---- qualities: global -> LDS; score the parked hits and deliver them
     const uint8_t *qsrc_ = nullptr;
-    uint32_t qbytes_ = 0;
-    const bool q_ahead = TK >= 3 && SCORES && quals_ahead(a, o0, o1, qsrc_, qbytes_); // (then match_lists_rows has started them)
+    uint32_t qbytes_ = 0, qlate_ = 0;
+    const bool q_ahead = TK >= 3 && SCORES && quals_ahead(a, o0, o1, stg_cap, qsrc_, qbytes_, qlate_); // (then match_lists_rows has started them)
     if (q_ahead) quals_landed();
     if (DEFER) {
         for (uint32_t g = 0; g < 64; g += GL) {
@@ -1059,7 +1080,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
 #endif
             if (q_ahead) {
                 wave_lds_sync();
-                l0 = ROWBUF_OFF;
+                l0 = quals_at(qlate_);
             } else {
                 wave_lds_sync();
                 if (SCORES && a.b.qual) l0 = stage_wave(stg, a.b.qual + gb, ge - gb, lane); // (fits: the bases of this group did)
