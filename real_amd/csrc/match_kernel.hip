@@ -10,25 +10,28 @@
 //   best/unique fold                        matchUniqueImplementation.cpp:97-160, 179-248
 //   or hit append of matchAll               matchAllImplementation.cpp:172-184
 //
-// Work decomposition: one lane per read, 256-thread workgroups, three waves per SIMD.
+// Work decomposition: one lane per read, a wave per tile of 64 reads.  The grid is as many 256-thread workgroups as the
+// device holds at a time (three per CU: three waves per SIMD); a wave takes tiles from a counter until none is left.
 //   front  the wave copies the bases of its 64 reads (one contiguous range of the caller's array) into its
 //          LDS region; every lane packs its own read into registers (32 bases per word), derives the seed
 //          halves of both strands; the reverse complement is computed in registers.
-//   match  per strand: the bucket-table entries of the six lists are requested together; the equal ranges
-//          are enumerated in list order and the entries that survive the partner filter go to the lane's
-//          queue in LDS (list-major, entry order = the reference's candidate order; a window reached
-//          through consecutive lists is one entry with a list mask); the queue is drained in order: seed
-//          window from the 2-bit text, popcount filters, whole-read Hamming distance.  With scores on a
-//          verified window and its update() events are parked.  Three table kinds feed this stage
-//          (match_lists: bucket starts; match_lists_fine: directory entries with partner digests or key
-//          fingerprints) and a fourth replaces it by lookups of lane groups (match_lists_rows).
-//   back   the wave copies the qualities of its reads through LDS the same way; all lanes score their
-//          parked windows together and replay their events into the fold / append them for matchAll.
+//   match  per strand: the equal ranges of the six lists are enumerated in list order and the entries that survive
+//          the partner filter go to the lane's queue in LDS (list-major, entry order = the reference's candidate
+//          order; a window reached through consecutive lists is one entry with a list mask); the queue is drained
+//          in order: seed window and the words of the whole read from the 2-bit text in one go (the next candidate's
+//          are requested before this one is looked at), popcount filters, whole-read Hamming distance.  With scores
+//          on a verified window and its update() events are parked.  Three table kinds feed this stage (match_lists:
+//          bucket starts; match_lists_fine: directory entries with partner digests or key fingerprints) and a
+//          fourth replaces it by lookups of lane groups (match_lists_rows: one 128-byte row = one line of HBM per
+//          lookup, the next list's rows in flight while this one is decoded).
+//   back   the qualities of the wave's reads come to LDS by LDS-DMA while the queues are drained for the last time
+//          (bucket rows; otherwise the wave copies them as it did the bases); all lanes score their parked windows
+//          together and replay their events into the fold / append them for matchAll.
 // The update() events of a read reach the fold in the canonical order (strand, list, position), which
 // matters because the fold is order dependent when scores are on.  Every index access is a
-// dependent random 8..48-byte read of a 128-byte line of an HBM-resident table: the kernel is bound by
-// the HBM lines it moves (20.7 per read with digest tables, 95 % of the sustainable line rate), not by
-// arithmetic (no MFMA: XOR/popcount and a short FP64 add chain).
+// dependent random read of a 128-byte line of an HBM-resident table: the kernel is bound by the HBM lines it
+// moves (13.6 per read with bucket rows on the C2 workload), not by arithmetic (no MFMA:
+// XOR/popcount and a short FP64 add chain).
 #include "match_common.h"
 #include <cstdlib>
 
@@ -49,14 +52,15 @@
 #define PH_NOW() 0u
 #endif
 #define EB 8  // index entries a lane requests per round trip while enumerating equal ranges
-#define MQ 16 // candidate queue slots per lane (LDS); a full queue is drained and refilled
+#define MQ 16 // candidate queue slots per lane (LDS) of the table kinds 0..2; a full queue is drained and refilled
 // LDS bytes of one wave: its candidate queue (MQ x 64 positions + lists, 6 x 64 cursors; the first 6.5 KiB) while
 // it matches; before and after, the staging area through which it reads the bases / qualities of its reads from
 // the batch.  9.5 KiB hold the 64 reads of a wave up to 151 bases each in one go; with the 8 KiB score table that
 // is 46 KiB per workgroup = three workgroups per CU, which is what the registers allow anyway.
 #define QUEUE_BYTES (MQ * 64u * 5u + 6u * 64u * 4u)
 __host__ __device__ constexpr uint32_t stg_bytes(int W, int TK) { return TK >= 3 ? 11008u : (W <= 4 ? QUEUE_BYTES : 9728u); }
-// bucket rows (table kind 3): a queue of MQR slots per lane, then the 64 rows of a list, 128 bytes each
+// bucket rows (table kind 3): a queue of MQR slots per lane (a read that needs more for one strand is handed over),
+// then the 64 rows of a list, 128 bytes each
 #define MQR 8u
 #define ROWBUF_OFF (MQR * 64u * 5u)
 #define BKX_OFF (ROWBUF_OFF + 64u * 128u) /* 64 bucket numbers, transposed for the piece loaders */
