@@ -372,6 +372,33 @@ def test_repeat_cliff_is_bit_exact_and_bounded_in_time(ora, seedl, kind, pb, sco
     m.close()
 
 
+@pytest.mark.parametrize("patl,shift", [(100, 0), (100, 4), (100, 7), (150, 0), (150, 5), (36, 3)])
+def test_device_batch_at_any_address(ora, patl, shift):
+    """Resident batches whose arrays start at any byte address (a slice of a larger device buffer): the qualities of a wave
+    travel by LDS-DMA only when their first byte lies at a multiple of 16 (match_kernel.hip: quals_ahead), in one piece up to
+    8 KiB per wave and in two above (150 bp reads); everything else is staged by the wave itself.  Same records either way."""
+    import torch
+    seedl = 32 if patl < 150 else 64
+    k = 3 if patl < 150 else 5
+    g = synth.random_genome(150_000, seed=300 + patl, n_frag=2, n_runs=4, repeats=10)
+    b = synth.sample_reads(g, 3000, patl, 0.02, seed=301 + shift)
+    p = ora.make_params(seedl=seedl, seedkmax=2, totalkmax=k, scores=1)
+    oinfo, oscore, _ = _oracle_unique(ora, None, g.sym, g.frag_start, seedl, 0, p, b.bases, b.qual, b.offsets)
+    m = UniqueMatcher(_opts(seedl, 2, k, 1), table_kind=3, prefix_bits=14)
+    m.set_text_symbols(0, g.sym, g.frag_start)
+    m.build_index_block()
+    n = b.n_reads
+    big_b = torch.zeros(n * patl + 64, dtype=torch.uint8, device="cuda")
+    big_q = torch.zeros(n * patl + 64, dtype=torch.uint8, device="cuda")
+    db, dq = big_b[shift:shift + n * patl], big_q[shift:shift + n * patl]
+    db.copy_(torch.from_numpy(b.bases)); dq.copy_(torch.from_numpy(b.qual))
+    info = torch.zeros(n, dtype=torch.int64, device="cuda")
+    score = torch.full((n,), float(np.float32(ora.NOSCORE_INIT)), dtype=torch.float32, device="cuda")
+    m.match_unique(db, dq, patl=patl, info=info, score=score, n_reads=n)
+    _compare_unique(info.cpu().numpy().view(np.uint64), score.cpu().numpy(), oinfo, oscore, 1)
+    m.close()
+
+
 @pytest.mark.parametrize("where", ["host", "device"])
 def test_fresh_batch_ignores_what_the_record_arrays_hold(ora, where):
     """real_hip_batch.fresh: info / score are outputs only; every read -- matched by a lane, handed to the wave matcher
