@@ -625,20 +625,24 @@ __device__ __forceinline__ void wave_lds_sync()
 // at a multiple of 16 and fit the place of the rows, has them brought there by LDS-DMA while it drains its queues for the
 // last time.  Decided from the offsets of the reads alone, at both places that need to know (nothing is carried along:
 // the scalar registers are all in use).
-__device__ __forceinline__ bool quals_ahead(const MatchArgs &a, uint64_t o0, uint64_t o1, uint32_t cap, const uint8_t *&src, uint32_t &nbytes, uint32_t &late)
+__device__ __forceinline__ bool quals_ahead(const MatchArgs &a, uint64_t o0, uint64_t o1, uint32_t cap, const uint8_t *&src, uint32_t &nbytes, uint32_t &late,
+                                            uint32_t &skew)
 {
     if (!a.b.qual || a.b.gl < 64) return false;
     const uint64_t gb = __shfl(o0, 0), ge = __shfl(o1, 63);
-    src = a.b.qual + gb;
-    nbytes = (uint32_t)(ge - gb);
+    // the pieces are 16 bytes at multiples of 16: they start with the `skew` bytes in front of the wave's first quality
+    // (bytes of the reads before it; a wave at the very start of an array that is not aligned itself stages as before)
+    skew = (uint32_t)((uintptr_t)(a.b.qual + gb) & 15u);
+    src = a.b.qual + gb - skew;
+    nbytes = (uint32_t)(ge - gb) + skew;
     // up to 8 KiB: everything into the place of the rows.  More (reads of 129 .. 170 bases): the bytes lie from STG_PAD on,
     // as stage_wave() puts them; what comes to lie under the queues -- the first `late` bytes -- follows when the queues
     // have been drained
     late = nbytes <= 64u * 128u ? 0u : ROWBUF_OFF - STG_PAD;
-    return ge >= gb && ge - gb <= cap && ((uintptr_t)src & 15u) == 0;
+    return ge >= gb && gb >= skew && ge - gb + skew <= cap;
 }
-// where they lie in the wave's region
-__device__ __forceinline__ uint32_t quals_at(uint32_t late) { return late ? STG_PAD : ROWBUF_OFF; }
+// where the first quality of the wave lies in its region
+__device__ __forceinline__ uint32_t quals_at(uint32_t late, uint32_t skew) { return (late ? STG_PAD : ROWBUF_OFF) + skew; }
 
 // every byte that quals_ahead()'s LDS-DMA brought is in LDS (and nothing of it can arrive after the wave has ended)
 __device__ __forceinline__ void quals_landed()
@@ -724,8 +728,8 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
 #define ISSUE_QUALS()                                                                                                                         \
     do {                                                                                                                                      \
         const uint8_t *qsrc;                                                                                                                  \
-        uint32_t qbytes, qlate;                                                                                                               \
-        if (quals_ahead(a, s.o0, s.o1, stg_bytes(W, 3) - STG_PAD - 32u, qsrc, qbytes, qlate)) {                                               \
+        uint32_t qbytes, qlate, qskew;                                                                                                        \
+        if (quals_ahead(a, s.o0, s.o1, stg_bytes(W, 3) - STG_PAD - 32u, qsrc, qbytes, qlate, qskew)) {                                             \
             wave_lds_sync();                                                                                                                  \
             const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)rowbuf);   \
             QUAL_DMA(qlate, lds0, qbytes - qlate, 9u)                                                                                         \
@@ -736,8 +740,8 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
 #define ISSUE_QUALS_LATE() /* the queues are drained: what lies in their place */                                                             \
     do {                                                                                                                                      \
         const uint8_t *qsrc;                                                                                                                  \
-        uint32_t qbytes, qlate;                                                                                                               \
-        if (quals_ahead(a, s.o0, s.o1, stg_bytes(W, 3) - STG_PAD - 32u, qsrc, qbytes, qlate) && qlate) {                                      \
+        uint32_t qbytes, qlate, qskew;                                                                                                        \
+        if (quals_ahead(a, s.o0, s.o1, stg_bytes(W, 3) - STG_PAD - 32u, qsrc, qbytes, qlate, qskew) && qlate) {                                     \
             wave_lds_sync();                                                                                                                  \
             const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)stg);      \
             QUAL_DMA(0u, lds0 + STG_PAD, qlate, 3u)                                                                                           \
@@ -1070,8 +1074,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
     }
     // ---- qualities: global -> LDS; score the parked hits and deliver them
     const uint8_t *qsrc_ = nullptr;
-    uint32_t qbytes_ = 0, qlate_ = 0;
-    const bool q_ahead = TK >= 3 && SCORES && quals_ahead(a, o0, o1, stg_cap, qsrc_, qbytes_, qlate_); // (then match_lists_rows has started them)
+    uint32_t qbytes_ = 0, qlate_ = 0, qskew_ = 0;
+    const bool q_ahead = TK >= 3 && SCORES && quals_ahead(a, o0, o1, stg_cap, qsrc_, qbytes_, qlate_, qskew_); // (then match_lists_rows has started them)
     if (q_ahead) quals_landed();
     if (DEFER) {
         for (uint32_t g = 0; g < 64; g += GL) {
@@ -1084,7 +1088,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
 #endif
             if (q_ahead) {
                 wave_lds_sync();
-                l0 = quals_at(qlate_);
+                l0 = quals_at(qlate_, qskew_);
             } else {
                 wave_lds_sync();
                 if (SCORES && a.b.qual) l0 = stage_wave(stg, a.b.qual + gb, ge - gb, lane); // (fits: the bases of this group did)
