@@ -53,6 +53,18 @@ CASES = {
     "l48_ragged": dict(genome=dict(n=30000, seed=11, n_frag=4, n_runs=3, repeats=5),
                        reads=[(60, 48, 0.0, 13), (60, 75, 0.02, 14), (60, 131, 0.03, 15), (20, 40, 0.0, 16)],
                        seedl=48, seedkmax=1, totalkmax=4, scores=1, n_list=0, n_read_prob=0.002),
+    # other seed lengths (RealOptions.cpp:439-443 makes every seed length a multiple of four, so the four segments are
+    # always equally long): l = 20 and 28 with 32-bit signatures, l = 36 -- the shortest seed with 64-bit ones; reads
+    # exactly as long as the seed; seedkmax 1
+    "l20_k4": dict(genome=dict(n=20000, seed=21, n_frag=2, n_runs=2, repeats=6), reads=[(200, 60, 0.03, 22)],
+                   seedl=20, seedkmax=2, totalkmax=4, scores=1, n_list=0),
+    "l28_s1_noscores": dict(genome=dict(n=50000, seed=23, n_frag=3, n_runs=3, repeats=8), reads=[(200, 100, 0.02, 24), (50, 28, 0.0, 25)],
+                            seedl=28, seedkmax=1, totalkmax=3, scores=0, n_list=0),
+    "l36_wide": dict(genome=dict(n=40000, seed=27, n_frag=2, n_runs=2, repeats=6, repeat_len=300), reads=[(200, 125, 0.02, 28)],
+                     seedl=36, seedkmax=2, totalkmax=5, scores=1, n_list=0),
+    # 250 bp reads (eight words per oriented read), seed 32, many mismatches allowed
+    "l32_250bp_k8": dict(genome=dict(n=60000, seed=29, n_frag=2, n_runs=3, repeats=6, repeat_len=500), reads=[(150, 250, 0.02, 30)],
+                         seedl=32, seedkmax=2, totalkmax=8, scores=1, n_list=0),
 }
 
 
@@ -104,7 +116,10 @@ def run_harness(g, b, case, d):
 def main():
     if not os.path.exists(HARNESS):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    only = set(sys.argv[1:])           # (names on the command line: only those cases are written)
     for name, case in CASES.items():
+        if only and name not in only:
+            continue
         g, b = make_inputs(case)
         with tempfile.TemporaryDirectory() as d:
             out = run_harness(g, b, case, d)
