@@ -705,7 +705,8 @@ int rh_index_build_device(real_hip_ctx *ctx, uint64_t first_window, uint64_t max
 // The matcher appends hits in wave order and counts them per read; a read has a handful of
 // hits, so: offsets = exclusive scan of the counts, scatter every raw record into its read's
 // segment, rank the records of a segment against each other (one thread per read; one
-// workgroup per read with more than ALL_SMALL hits).  No global sort.
+// workgroup per read with more than ALL_SMALL hits).  No global sort.  A read with one hit -- most
+// of those that have any -- needs neither: its record goes straight from the raw list to its place.
 // ---------------------------------------------------------------------------
 #define ALL_SMALL 32u
 
@@ -730,31 +731,42 @@ __device__ __forceinline__ real_hip_hit hit_record(const uint4 &h)
     return o;
 }
 
-__global__ void all_scatter_kernel(const uint4 *__restrict__ raw, uint64_t n, const uint64_t *__restrict__ off,
-                                   uint32_t *__restrict__ cursor, uint4 *__restrict__ seg)
+// most reads that have a hit have exactly one: its record goes straight to its place.  The hits of the others are
+// collected in their segment (cursor[] counts them; it is all zero between two calls) and the read is listed once.
+__global__ void all_scatter_kernel(const uint4 *__restrict__ raw, uint64_t n, const uint64_t *__restrict__ off, const uint32_t *__restrict__ cnt,
+                                   uint32_t *__restrict__ cursor, uint4 *__restrict__ seg, real_hip_hit *__restrict__ out,
+                                   uint32_t *__restrict__ multi_list, unsigned long long *multi_count)
 {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint4 h = raw[i];
-    seg[off[h.x] + atomicAdd(&cursor[h.x], 1u)] = h;
+    const uint64_t o = off[h.x];
+    if (cnt[h.x] == 1u) { out[o] = hit_record(h); return; }
+    const uint32_t slot = atomicAdd(&cursor[h.x], 1u);
+    seg[o + slot] = h;
+    if (slot == 0) multi_list[atomicAdd(multi_count, 1ull)] = h.x;
 }
 
-__global__ void all_rank_kernel(const uint4 *__restrict__ seg, const uint64_t *__restrict__ off, uint64_t n_reads,
+__global__ void all_rank_kernel(const uint4 *__restrict__ seg, const uint64_t *__restrict__ off, const uint32_t *__restrict__ multi_list,
+                                const unsigned long long *__restrict__ multi_count, uint32_t *__restrict__ cursor,
                                 real_hip_hit *__restrict__ out, uint32_t *__restrict__ big_list, unsigned long long *big_count)
 {
-    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_reads) return;
-    const uint64_t o = off[r];
-    const uint32_t c = (uint32_t)(off[r + 1] - o);
-    if (c > ALL_SMALL) { big_list[atomicAdd(big_count, 1ull)] = (uint32_t)r; return; }
-    for (uint32_t i = 0; i < c; ++i) {
-        const uint4 h = seg[o + i];
-        uint32_t rank = 0;
-        for (uint32_t j = 0; j < c; ++j) {
-            const uint4 g = seg[o + j];
-            rank += (hit_less(g, h) || (j < i && !hit_less(h, g))) ? 1u : 0u;
+    const uint64_t nm = *multi_count;
+    for (uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; m < nm; m += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = multi_list[m];
+        cursor[r] = 0; // (for the next call)
+        const uint64_t o = off[r];
+        const uint32_t c = (uint32_t)(off[r + 1] - o);
+        if (c > ALL_SMALL) { big_list[atomicAdd(big_count, 1ull)] = (uint32_t)r; continue; }
+        for (uint32_t i = 0; i < c; ++i) {
+            const uint4 h = seg[o + i];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < c; ++j) {
+                const uint4 g = seg[o + j];
+                rank += (hit_less(g, h) || (j < i && !hit_less(h, g))) ? 1u : 0u;
+            }
+            out[o + rank] = hit_record(h);
         }
-        out[o + rank] = hit_record(h);
     }
 }
 
@@ -864,19 +876,22 @@ int rh_all_finish(real_hip_ctx *ctx, uint64_t n_raw, uint64_t n_reads, real_hip_
     }
     if (n_raw) {
         if ((rc = rh_reserve(ctx, ctx->keys_a, n_raw * sizeof(uint4)))) return rc;       // the per-read segments
-        if ((rc = rh_reserve(ctx, ctx->vals_a, n_reads * 4))) return rc;                  // scatter cursors
-        if ((rc = rh_reserve(ctx, ctx->big_list, n_reads * 4 + 8))) return rc;
-        unsigned long long *big_count = (unsigned long long *)((uint8_t *)ctx->big_list.p + n_reads * 4);
-        RH_HIP(ctx, hipMemsetAsync(ctx->vals_a.p, 0, n_reads * 4, ctx->stream));
-        RH_HIP(ctx, hipMemsetAsync(big_count, 0, 8, ctx->stream));
+        if (n_reads * 4 > ctx->all_cursor.cap) {                                          // scatter cursors: zero between two calls
+            if ((rc = rh_reserve(ctx, ctx->all_cursor, n_reads * 4))) return rc;
+            RH_HIP(ctx, hipMemsetAsync(ctx->all_cursor.p, 0, ctx->all_cursor.cap, ctx->stream));
+        }
+        if ((rc = rh_reserve(ctx, ctx->big_list, n_reads * 8 + 16))) return rc;          // reads with more than one hit; with more than ALL_SMALL
+        uint32_t *multi_list = (uint32_t *)ctx->big_list.p, *big_list = multi_list + n_reads;
+        unsigned long long *counts = (unsigned long long *)((uint8_t *)ctx->big_list.p + n_reads * 8);
+        RH_HIP(ctx, hipMemsetAsync(counts, 0, 16, ctx->stream));
         const uint4 *raw = (const uint4 *)ctx->raw.p;
         uint4 *seg = (uint4 *)ctx->keys_a.p;
         hipLaunchKernelGGL(all_scatter_kernel, dim3((unsigned)((n_raw + 255) / 256)), dim3(256), 0, ctx->stream, raw, n_raw,
-                           (const uint64_t *)off, (uint32_t *)ctx->vals_a.p, seg);
-        hipLaunchKernelGGL(all_rank_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, ctx->stream, (const uint4 *)seg,
-                           (const uint64_t *)off, n_reads, d_out, (uint32_t *)ctx->big_list.p, big_count);
+                           (const uint64_t *)off, (const uint32_t *)cnt, (uint32_t *)ctx->all_cursor.p, seg, d_out, multi_list, counts);
+        hipLaunchKernelGGL(all_rank_kernel, dim3(2048), dim3(256), 0, ctx->stream, (const uint4 *)seg, (const uint64_t *)off,
+                           (const uint32_t *)multi_list, (const unsigned long long *)counts, (uint32_t *)ctx->all_cursor.p, d_out, big_list, counts + 1);
         hipLaunchKernelGGL(all_rank_big_kernel, dim3(1024), dim3(256), 0, ctx->stream, seg, (uint4 *)ctx->raw.p, (const uint64_t *)off,
-                           (const uint32_t *)ctx->big_list.p, (const unsigned long long *)big_count, d_out);
+                           (const uint32_t *)big_list, (const unsigned long long *)(counts + 1), d_out);
     }
     RH_HIP(ctx, hipGetLastError());
     return REAL_HIP_OK;

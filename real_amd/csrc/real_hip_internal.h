@@ -161,7 +161,7 @@ struct real_hip_ctx {
     // read ingestion (read_parse.hip)
     DevBuf p_text, p_nl, p_scal, p_spans, p_off, p_len1, p_bases, p_qual;
     // matchAll workspace
-    DevBuf raw, raw_count, hit_cnt, big_list, keys_a, keys_b, vals_a, vals_b, sort_tmp, hit_off, s_hits;
+    DevBuf raw, raw_count, hit_cnt, big_list, all_cursor, keys_a, keys_b, vals_a, vals_b, sort_tmp, hit_off, s_hits;
 
     // where the wall time of an index build goes (real_hip_index_build_stats)
     double   alloc_ms = 0, free_ms = 0, build_wall_ms = 0;
