@@ -55,12 +55,16 @@ def algorithmic_bytes(c, patl, seedl, scores, hit_bytes_out=0):
 
 
 def kernel_source_hash():
-    """sha256 over the sources of the match kernel: profiles/traffic.json records the hash it was measured with,
-    and a figure measured on another kernel is not reported."""
+    """sha256 over the sources of the match kernel with comments and white space taken out: profiles/traffic.json records
+    the hash it was measured with, and a figure measured on another kernel is not reported."""
+    import re
     h = hashlib.sha256()
     for f in ("match_kernel.hip", "match_common.h", "kernel_common.h", "real_hip_internal.h"):
-        with open(os.path.join(ROOT, "real_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
+        with open(os.path.join(ROOT, "real_amd", "csrc", f), "r", encoding="utf-8") as fh:
+            src = fh.read()
+        src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)      # block comments
+        src = re.sub(r"//[^\n]*", " ", src)                    # line comments (no string of these files holds "//")
+        h.update(" ".join(src.split()).encode())
     return h.hexdigest()[:16]
 
 

@@ -999,6 +999,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
     asm volatile("" : "+v"(tid));
     // ... and the kernel's arguments are read from the kernel argument segment where they are used (scalar loads that hit
     // the scalar cache), tile by tile: all of them hoisted in front of the loop do not fit the scalar registers
+    // (MatchArgs is the kernel's only parameter: it lies at offset 0 of the segment)
     const __attribute__((address_space(4))) MatchArgs *pa = (const __attribute__((address_space(4))) MatchArgs *)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(pa));
     const MatchArgs &a = *(const MatchArgs *)pa;
