@@ -372,6 +372,34 @@ def test_repeat_cliff_is_bit_exact_and_bounded_in_time(ora, seedl, kind, pb, sco
     m.close()
 
 
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 257, 1000])
+def test_batch_sizes_around_the_tile_of_64_reads(ora, n):
+    """The waves of the resident grid take tiles of 64 reads from a counter: batches of less than a tile, of whole tiles
+    and with a partial last tile, packed bases and bytes."""
+    g = synth.random_genome(80_000, seed=400, n_frag=2, n_runs=2, repeats=6)
+    b = synth.sample_reads(g, n, 100, 0.02, seed=401 + n)
+    p = ora.make_params(seedl=32, seedkmax=2, totalkmax=3, scores=1)
+    oinfo, oscore, octr = _oracle_unique(ora, None, g.sym, g.frag_start, 32, 0, p, b.bases, b.qual, b.offsets)
+    m = UniqueMatcher(_opts(32, 2, 3, 1), table_kind=3, prefix_bits=13)
+    m.set_text_symbols(0, g.sym, g.frag_start)
+    m.build_index_block()
+    info, score = m.match_unique(b.bases, b.qual, patl=100)
+    _compare_unique(info, score, oinfo, oscore, 1)
+    c = m.counters()
+    for kk in ("reads", "lookups", "candidates", "seedpass", "hits"):
+        assert c[kk] == octr[kk], (kk, c[kk], octr[kk])
+    if n % 4 == 0:                                           # the same batch with the bases 2-bit packed
+        q4 = b.bases.reshape(-1, 4)
+        pk = ((q4[:, 0] << 6) | (q4[:, 1] << 4) | (q4[:, 2] << 2) | q4[:, 3]).astype(np.uint8)
+        nfl = np.zeros((n + 7) // 8, dtype=np.uint8)
+        bad = np.nonzero((b.bases.reshape(n, 100) > 3).any(axis=1))[0]
+        np.bitwise_or.at(nfl, bad // 8, (1 << (bad % 8)).astype(np.uint8))
+        pk = ((np.minimum(q4[:, 0], 3) << 6) | (np.minimum(q4[:, 1], 3) << 4) | (np.minimum(q4[:, 2], 3) << 2) | np.minimum(q4[:, 3], 3)).astype(np.uint8)
+        info2, score2 = m.match_unique(pk, b.qual, patl=100, n_reads=n, packed=True, nflags=nfl)
+        _compare_unique(info2, score2, oinfo, oscore, 1)
+    m.close()
+
+
 @pytest.mark.parametrize("patl,shift", [(100, 0), (100, 4), (100, 7), (150, 0), (150, 5), (36, 3)])
 def test_device_batch_at_any_address(ora, patl, shift):
     """Resident batches whose arrays start at any byte address (a slice of a larger device buffer): the qualities of a wave
