@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""How the matcher takes a genome with repeats (the BASELINE genome is i.i.d. random and has none): a synthetic genome in
+which a given share of the positions lies in families of exact copies of 1 kbp segments, reads sampled uniformly.  Prints
+the step time, the time of the lane-per-read and of the wave-per-read kernel, and the share of reads handed over.
+
+    python bench_support/repeat_genome.py [--genome-mbp 1000] [--reads 20000000] [--share 0.1] [--copies 5]
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--genome-mbp", type=float, default=1000)
+    ap.add_argument("--reads", type=int, default=20_000_000)
+    ap.add_argument("--share", type=float, default=0.1, help="share of the genome that lies in repeat copies")
+    ap.add_argument("--copies", type=int, default=5)
+    ap.add_argument("--seg", type=int, default=1000)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--errprob", type=float, default=0.02)
+    ap.add_argument("--table-kind", type=int, default=0)
+    ap.add_argument("--prefix-bits", type=int, default=0)
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    import bench
+    from real_amd import lib as rlib
+    from real_amd.matcher import HipMatcher, RealOptions
+    dev = torch.device("cuda", 0)
+    G, n, patl = int(args.genome_mbp * 1e6), args.reads, 100
+    sym = bench.gen_genome(torch, G, 3, dev)
+    fam = int(G * args.share / (args.copies * args.seg))
+    g = torch.Generator(device="cpu"); g.manual_seed(7)
+    ar = torch.arange(args.seg, device=dev)
+    src = (torch.randint(0, G - args.seg, (fam,), generator=g)).to(dev)
+    for c in range(args.copies - 1):           # every family: the source segment and copies - 1 exact copies elsewhere
+        dst = (torch.randint(0, G - args.seg, (fam,), generator=g)).to(dev)
+        sym[(dst[:, None] + ar[None, :]).reshape(-1)] = sym[(src[:, None] + ar[None, :]).reshape(-1)]
+    m = HipMatcher(RealOptions(seedl=32, seedkmax=2, totalkmax=3, scores=True).normalise(), device=0, table_kind=args.table_kind, prefix_bits=args.prefix_bits)
+    m.set_text_symbols(0, sym, np.array([0, G], dtype=np.uint64))
+    m.build_index_block()
+    bases, qual, _, _ = bench.gen_reads(torch, sym, n, patl, args.errprob, 4, dev)
+    del sym
+    pk = bench.pack_bases(torch, bases, n, patl)
+    dt, ctr, (ms, ln), (rms, rn), (info, _) = bench.timed_unique(torch, None, m, rlib, pk, qual, patl, n, args.steps, 1, 1, 0, dev, dev, packed=True)
+    st = (info >> 61) & 7
+    print(json.dumps({"genome_mbp": args.genome_mbp, "reads": n, "share_in_repeats": args.share, "copies": args.copies,
+                      "ms_per_step": dt / args.steps * 1e3, "reads_per_s": n * args.steps / dt,
+                      "lane_kernel_ms": ms / max(ln, 1), "wave_kernel_ms": rms / max(rn, 1),
+                      "table_kind": m.table_kind, "prefix_bits": m.prefix_bits, "handed_over_frac": ctr["handed_over"] / max(ctr["reads"], 1),
+                      "nonunique_frac": float((st == 4).float().mean().item()), "unique_frac": float(((st == 1) | (st == 2)).float().mean().item())}))
+
+
+if __name__ == "__main__":
+    main()

@@ -69,9 +69,9 @@ static_assert(BKX_OFF + 256u <= stg_bytes(4, 3) && ROWBUF_OFF % 16 == 0 && QUEUE
 #ifndef RH_KEEP_TW_MAXW
 #define RH_KEEP_TW_MAXW 4
 #endif
-#define NPEND 2      // verified locations a lane parks until their scores are computed (flush_pending)
+#define NPEND 4      // verified locations a lane parks until their scores are computed (flush_pending)
 #define PEND_EV 32   // update() events parked with them
-#define SLOT_NONE 3u
+#define SLOT_NONE 7u
 #define PEND_OVF 0xffu // p_n of a read that is handed over to the wave-cooperative matcher (match_wave.hip)
 #define BIG_T 48u      // an equal range / bucket scan longer than this many entries is not walked by one lane: hand-over
 
@@ -102,7 +102,8 @@ struct LaneState {
     uint32_t p_pos[NPEND], p_meta[NPEND]; // text position; k | strand << 8 | fragment << 16
     uint64_t p_tw[W <= RH_KEEP_TW_MAXW ? W : 1]; // aligned text words of pending location 0 (kept for reads of up to 128 bases;
                                           // longer ones read the text again when they score: the registers are worth more)
-    uint32_t p_n, p_nev, p_ev, cslot;     // locations, events, 1 bit per event (= location), slot of the memo
+    uint32_t p_n, p_nev, cslot;           // locations, events, slot of the memo
+    uint64_t p_ev;                        // 2 bits per event: its location
     uint32_t nhit; // matchAll: hits appended for this read
     // work counters of this read, packed (a register each would cost six of the 168): cA = L:4 | V:12 | S:12, cB = P:11 | C:11 | H:10.
     // No field overflows without the read being handed over -- a lane walks at most BIG_T entries of each of its 12 equal
@@ -142,11 +143,12 @@ __device__ __forceinline__ void deliver(const MatchArgs &a, LaneState<W, SCORES,
 template <int W, bool SCORES, bool ALL, class Row>
 __device__ __forceinline__ void flush_pending(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL, const Row &qrow)
 {
-    float sc[NPEND] = {1.0f, 1.0f};
+    float sc0 = 1.0f, sc1 = 1.0f, sc2 = 1.0f, sc3 = 1.0f; // (scalars and selects: a run-time index would send them through scratch memory)
 #pragma unroll 1
     for (uint32_t j = 0; j < s.p_n; ++j) {
         if (!SCORES || (RH_ABLATE & 1)) break; // ComputeScore<...,false>: 1.0f (ComputeScore.hpp:31-45)
-        const uint32_t pos = j ? s.p_pos[1] : s.p_pos[0], meta = j ? s.p_meta[1] : s.p_meta[0];
+        const uint32_t pos = j == 0 ? s.p_pos[0] : j == 1 ? s.p_pos[1] : j == 2 ? s.p_pos[2] : s.p_pos[3];
+        const uint32_t meta = j == 0 ? s.p_meta[0] : j == 1 ? s.p_meta[1] : j == 2 ? s.p_meta[2] : s.p_meta[3];
         const uint32_t inv = (meta >> 8) & 1;
         uint64_t Ow[W], tw[W];
         if ((int)inv == s.inv) {
@@ -158,7 +160,7 @@ __device__ __forceinline__ void flush_pending(const MatchArgs &a, LaneState<W, S
         if (j == 0 && W <= RH_KEEP_TW_MAXW) {
 #pragma unroll
             for (int i = 0; i < W; ++i) tw[i] = s.p_tw[W <= RH_KEEP_TW_MAXW ? i : 0];
-        } else { // second location of a read (any location of a long read): the text is read again
+        } else { // a further location of a read (any location of a long read): the text is read again
             const uint64_t wi = pos >> 5;
             const unsigned sh = 2u * (pos & 31);
             uint64_t t[W + 2];
@@ -172,24 +174,30 @@ __device__ __forceinline__ void flush_pending(const MatchArgs &a, LaneState<W, S
             for (int i = 0; i < W; ++i) tw[i] = sh ? ((t[i] << sh) | (t[i + 1] >> (64 - sh))) : t[i];
         }
         const float v = score_location<W>(sLL, Ow, tw, s.patl, qrow, a.b.qual != nullptr, inv);
-        if (j) sc[1] = v; else sc[0] = v;
+        if (j == 0) sc0 = v; else if (j == 1) sc1 = v; else if (j == 2) sc2 = v; else sc3 = v;
     }
 #pragma unroll 1
     for (uint32_t e = 0; e < s.p_nev; ++e) {
-        const uint32_t j = (s.p_ev >> e) & 1u;
-        deliver<W, SCORES, ALL>(a, s, j ? s.p_pos[1] : s.p_pos[0], j ? s.p_meta[1] : s.p_meta[0], j ? sc[1] : sc[0]);
+        const uint32_t j = (uint32_t)(s.p_ev >> (2 * e)) & 3u;
+        deliver<W, SCORES, ALL>(a, s, j == 0 ? s.p_pos[0] : j == 1 ? s.p_pos[1] : j == 2 ? s.p_pos[2] : s.p_pos[3],
+                                j == 0 ? s.p_meta[0] : j == 1 ? s.p_meta[1] : j == 2 ? s.p_meta[2] : s.p_meta[3],
+                                j == 0 ? sc0 : j == 1 ? sc1 : j == 2 ? sc2 : sc3);
     }
 }
 
 // one member of a bucket whose fingerprint equals the read's: the body of the candidate loop
 // of ::match (match.hpp:383-413)
-// A survivor of the partner filter goes to the lane's queue.  The same window reached through the next list right
-// after (the true locus is found through 4.4 lists per read) only sets that list's bit in the entry: the drain then
-// runs once per window instead of once per (window, list), and the order of the update() events stays the same.
+// A survivor of the partner filter goes to the lane's queue.  A window that is in the queue already -- the true locus is
+// found through 4.4 lists per read, the copies of a repeat through as many each -- only gets that list's bit set in its
+// entry: the drain then runs once per window instead of once per (window, list).  The entries stand in the order in which
+// the windows were reached first, the canonical order of their first update() events; every later update() of a window
+// that has had one leaves the record as it is (kernel_common.h: fold_update; matchAll keeps the first one only), so the
+// record does not depend on where those are delivered.
 __device__ __forceinline__ void queue_push(uint32_t *q_pos, uint8_t *q_la, uint32_t &qn, uint32_t pos, int la)
 {
-    if (qn && q_pos[(qn - 1) * 64] == pos) q_la[(qn - 1) * 64] |= (uint8_t)(1u << la);
-    else { q_pos[qn * 64] = pos; q_la[qn * 64] = (uint8_t)(1u << la); qn++; }
+    for (uint32_t k = qn; k-- > 0;) // (from the last entry: that is where the true locus of the previous list is)
+        if (q_pos[k * 64] == pos) { q_la[k * 64] |= (uint8_t)(1u << la); return; }
+    q_pos[qn * 64] = pos; q_la[qn * 64] = (uint8_t)(1u << la); qn++;
 }
 
 // The text a candidate needs: the two (three) words of its seed window and the words of text[pos, pos + patl).  They are
@@ -257,7 +265,16 @@ __device__ __forceinline__ void process_loaded(const MatchArgs &a, LaneState<W, 
     if (rpos < so) return; // match.hpp:393
     const uint32_t pos = rpos - so;
     bool reg = false; // a location verified here for the first time
-    if (pos != s.cpos) {
+    uint32_t parked = SLOT_NONE; // ... or one that is parked already (reached again after other windows: a repeat)
+    if (DEFER && pos != s.cpos) {
+#pragma unroll
+        for (uint32_t j = 0; j < NPEND; ++j)
+            if (j < s.p_n && s.p_pos[j] == pos && ((s.p_meta[j] >> 8) & 1u) == (uint32_t)s.inv) parked = j;
+    }
+    if (parked != SLOT_NONE) {
+        const uint32_t meta0 = parked == 0 ? s.p_meta[0] : parked == 1 ? s.p_meta[1] : parked == 2 ? s.p_meta[2] : s.p_meta[3];
+        s.cpos = pos; s.cok = true; s.ck = meta0 & 0xffu; s.cscore = 1.0f; s.cfrag = meta0 >> 16; s.cslot = parked;
+    } else if (pos != s.cpos) {
         s.cpos = pos;
         s.cok = false;
         s.addV(1u);
@@ -287,7 +304,9 @@ __device__ __forceinline__ void process_loaded(const MatchArgs &a, LaneState<W, 
         if (DEFER) { // the score is computed later (flush_pending): park the location
             if (s.p_n == NPEND) { s.p_n = PEND_OVF; return; } // out of room => the read is handed over
             const uint32_t meta0 = total | ((uint32_t)s.inv << 8) | (frag << 16);
-            if (s.p_n) { s.p_pos[1] = pos; s.p_meta[1] = meta0; }
+            if (s.p_n == 1) { s.p_pos[1] = pos; s.p_meta[1] = meta0; }
+            else if (s.p_n == 2) { s.p_pos[2] = pos; s.p_meta[2] = meta0; }
+            else if (s.p_n == 3) { s.p_pos[3] = pos; s.p_meta[3] = meta0; }
             else {
                 s.p_pos[0] = pos; s.p_meta[0] = meta0;
                 if (SCORES && W <= RH_KEEP_TW_MAXW) {
@@ -318,7 +337,7 @@ __device__ __forceinline__ void process_loaded(const MatchArgs &a, LaneState<W, 
     }
     // park the events (they all refer to the memo's slot); out of room => the read is handed over
     if (s.p_nev + ne > PEND_EV) { s.p_n = PEND_OVF; return; }
-    if (s.cslot) s.p_ev |= ((ne >= 32 ? 0xffffffffu : ((1u << ne) - 1u)) << s.p_nev);
+    s.p_ev |= (((uint64_t)s.cslot * 0x5555555555555555ull) & (ne >= 32 ? ~0ull : ((1ull << (2 * ne)) - 1ull))) << (2 * s.p_nev);
     s.p_nev += ne;
 }
 
@@ -833,8 +852,8 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
         }
         const uint32_t rk = wide ? rh_fp16(r) : (r >> (pbits - p16)); // what the 16 key bits of a row entry are compared with
         // the entries of the lanes' key groups, one per lane and step, without branches on the way: a survivor of the
-        // partner filter goes to the lane's queue; the same window reached through the next list right after only sets
-        // that list's bit -- the lane's last queue entry is kept in registers, nothing is read back.  A lane that needs
+        // partner filter goes to the lane's queue; a window that is in the queue already only gets this list's bit set
+        // (the lane's last queue entry is kept in registers: for it nothing is read back).  A lane that needs
         // more than MQR queue slots for one strand (repeat-rich loci only) hands its read over: the queues are drained
         // once, behind the lists, where the registers that hold the rows in flight are free again.
         while (__any(e_j < e_cnt)) {
@@ -855,6 +874,10 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
             // known mismatches => rejected without touching the text (exact: the full count can only be larger)
             bool pass = step && (wide ? (x == 0u) : (__popc(((x >> 1) | x) & 0x55555555u) <= a.seedkmax));
             const bool merge = pass && qn && pos == q_last;
+            if (pass && !merge && qn >= 2) { // (repeats: a window that stands further up in the queue gets this list's bit there)
+                for (uint32_t k = 0; k + 1 < qn; ++k)
+                    if (q_pos[k * 64] == pos) { q_la[k * 64] |= (uint8_t)(1u << la); pass = false; break; }
+            }
             if (pass && !merge && qn == MQR) { s.p_n = PEND_OVF; e_cnt = 0; pass = false; } // (match_wave.hip takes the read)
             const uint32_t slot = merge ? qn - 1 : qn;
             const uint32_t lav = (merge ? q_lastla : 0u) | (1u << la);

@@ -18,7 +18,7 @@
 // entries themselves.
 #include "match_common.h"
 
-#define WV_W RH_MAXW // the read sits in registers, up to REAL_HIP_MAX_PATL bases
+#define WV_W RH_MAXW // words of a read that the lane-per-read kernels take (REAL_HIP_MAX_PATL bases): the short form of this kernel holds as many
 
 struct WaveRange {
     const uint2 *E;      // entries {key, pos} in an entry array, or
@@ -39,7 +39,7 @@ __device__ __forceinline__ uint64_t pick4(uint64_t m0, uint64_t m1, uint64_t m2,
     return x == 0 ? m0 : x == 1 ? m1 : x == 2 ? m2 : m3;
 }
 
-// the equal range of list la for the oriented read with seed halves (shi, slo); everything here is wave-uniform
+// the equal range of list la for the oriented read with seed halves (shi, slo) (called by twelve lanes at once, each for its own list and strand)
 __device__ __forceinline__ WaveRange wave_lookup(const MatchArgs &a, uint64_t shi, uint64_t slo, int la)
 {
     WaveRange R;
@@ -192,13 +192,27 @@ __device__ __forceinline__ float long_score(const double *sLL, const uint64_t *_
     return (float)raw;
 }
 
-template <bool SCORES, bool ALL>
-__global__ __launch_bounds__(256) void match_wave_kernel(MatchArgs a)
+// the score of the location at pos if the wave has computed it for this strand already (n = wave-uniform number of entries)
+__device__ __forceinline__ bool memo_score(const uint32_t *mpos, const float *msc, uint32_t n, uint32_t pos, float &sc)
 {
-    constexpr int W = WV_W;
+    bool found = false;
+    for (uint32_t m = 0; m < n; ++m)
+        if (mpos[m] == pos) { sc = msc[m]; found = true; }
+    return found;
+}
+
+// LONG: the batch may hold reads longer than the registers of a lane hold (REAL_HIP_MAX_PATL): 32 KiB of LDS per workgroup
+// for their words, three workgroups per CU.  Without them the kernel needs 10 KiB, and eight workgroups share a CU.
+#define WV_MEMO 8u // scores of the locations a wave has scored for the strand it is on: a window is reached through up to six lists
+template <bool SCORES, bool ALL, bool LONG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void match_wave_kernel(MatchArgs a)
+{
+    constexpr uint32_t QL = LONG ? WV_QL : 32u * WV_W; // qualities of a read that has at most this many bases are staged in LDS
     __shared__ double sLL[SCORES ? RH_LL_SLOTS : 1];
-    __shared__ uint64_t sLong[4][2][WV_NWL]; // per wave: the words of a long read, straight and reverse-complemented
-    __shared__ uint8_t sQual[4][WV_QL];       // ... and its qualities, if it has at most WV_QL bases (longer: from global memory)
+    __shared__ uint64_t sLong[4][2][LONG ? WV_NWL : WV_W]; // per wave: the words of its read, straight and reverse-complemented
+    __shared__ __attribute__((aligned(16))) uint8_t sQual[4][16 + QL + 16]; // ... the qualities of the read (16 bytes in front and behind: LdsRow reads whole dwords)
+    __shared__ uint32_t sMemoPos[4][WV_MEMO];
+    __shared__ float sMemoSc[4][WV_MEMO];
     if (SCORES) {
         for (int i = threadIdx.x; i < 1024; i += 256) sLL[i] = a.LL[i];
         if (threadIdx.x == 0) sLL[RH_LL_ZERO] = 0.0;
@@ -216,24 +230,22 @@ __global__ __launch_bounds__(256) void match_wave_kernel(MatchArgs a)
         const uint64_t r = a.ovf_list[it];
         const uint64_t o0 = a.b.off ? a.b.off[r] : r * (uint64_t)a.b.upatl;
         const uint32_t patl = a.b.off ? (uint32_t)(a.b.off[r + 1] - o0) : a.b.upatl;
-        uint64_t O[W];
-        const bool lng = patl > 32u * W; // (wave-uniform) the read lives in LDS words instead of O[]
+        // The read sits in the wave's LDS as words of 32 bases, straight and reverse-complemented, whatever its length; every
+        // lane walks the words of its own candidate in run-time loops (an LDS word is the same address in all lanes: a
+        // broadcast).  Few registers per lane that way: many waves per CU, and this kernel lives on waves in flight.
         uint64_t *const sO = sLong[threadIdx.x >> 6][0], *const sR = sLong[threadIdx.x >> 6][1];
         const uint32_t nw = (patl + 31) >> 5;
         // The matcher hands over reads it has packed (eligible) and reads it could not even stage (too long for its
         // registers, or next to such a read): eligibility (matchUniqueImplementation.cpp:376-394) is settled here.
-        bool elig = patl >= l && patl <= REAL_HIP_MAX_PATL_LONG;
+        bool elig = patl >= l && patl <= (LONG ? REAL_HIP_MAX_PATL_LONG : 32u * WV_W);
+        if (!LONG && patl > 32u * WV_W && lane == 0) atomicOr(a.err_flags, 1u); // (the host picks LONG from the longest read of the batch: an error)
         if (elig && a.b.packed && a.b.nflags && ((a.b.nflags[r >> 3] >> (r & 7)) & 1)) elig = false;
-        if (elig && !lng) {
-            if (a.b.packed) pack_read_packed<W>(GlobalRow{a.b.bases + (o0 >> 2)}, patl, (uint32_t)o0 & 3u, O);
-            else elig = pack_read<W>(GlobalRow{a.b.bases + o0}, patl, O); // (the same in every lane)
-        } else if (elig) {
+        uint64_t O[2] = {0ull, 0ull}; // (the seed halves come from the first two words)
+        if (elig) {
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // (the previous read's words are no longer in use)
             __builtin_amdgcn_wave_barrier();
             bool bad = false;
             for (uint32_t j = lane; j < nw; j += 64) sO[j] = long_word(a, o0, patl, j, &bad);
-            if (SCORES && a.b.qual && patl <= WV_QL) // the scoring loop reads a quality per base: from LDS, not one global load each
-                for (uint32_t i = lane; i < patl; i += 64) sQual[threadIdx.x >> 6][i] = a.b.qual[o0 + i];
             elig = !__any(bad);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -246,11 +258,20 @@ __global__ __launch_bounds__(256) void match_wave_kernel(MatchArgs a)
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int j = 0; j < W; ++j) O[j] = j < 2 ? sO[(uint32_t)j < nw ? j : 0] : 0ull; // (the seed halves come from the first two words)
-            if (nw < 2) O[1] = 0;
+            O[0] = sO[0];
+            O[1] = nw >= 2 ? sO[1] : 0ull;
         }
         if (!elig) continue; // skipped like the reference skips it; the matcher has written its hit count 0
+        // the qualities of the read: the scoring loop reads one per base -- from LDS, not one global load each
+        uint8_t *const qst = sQual[threadIdx.x >> 6];
+        const bool q_lds = SCORES && a.b.qual && patl <= QL;
+        if (q_lds) {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // (the previous read's are no longer in use)
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t i = lane; i < patl; i += 64) qst[16 + i] = a.b.qual[o0 + i];
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
         const uint64_t lastmask = ~0ull << (64 - 2 * (patl - 32 * (nw - 1)));
         const float eps = (float)(a.filter_mult * (double)patl); // RealOptions.hpp:74-77
         uint64_t info = 0;
@@ -261,19 +282,19 @@ __global__ __launch_bounds__(256) void match_wave_kernel(MatchArgs a)
         }
         uint32_t nhit = 0;
         uint64_t shi, slo, rhi, rlo;
-        seed_halves<W>(O, l, shi, slo, rhi, rlo);
+        seed_halves<2>(O, l, shi, slo, rhi, rlo);
         if (lane == 0) cR++;
+        // the twelve equal ranges of the read, one per lane and all at once: their bucket bounds / rows / binary searches are
+        // chains of dependent loads that would otherwise follow each other (lane 6 inv + la holds the range of list la)
+        WaveRange RL;
+        {
+            const uint32_t q = lane < 12 ? lane : 0u;
+            RL = wave_lookup(a, q >= 6 ? rhi : shi, q >= 6 ? rlo : slo, (int)(q >= 6 ? q - 6 : q));
+        }
         for (int inv = 0; inv < 2; ++inv) {
-            if (inv) { // transposed pattern, Pattern.hpp:105-128
-                if (!lng) {
-                    uint64_t Rv[W];
-                    revcomp_words<W>(O, Rv, patl);
-#pragma unroll
-                    for (int j = 0; j < W; ++j) O[j] = Rv[j];
-                }
-                shi = rhi; slo = rlo;
-            }
-            const uint64_t *const cur = inv ? sR : sO; // (long reads)
+            if (inv) { shi = rhi; slo = rlo; } // transposed pattern, Pattern.hpp:105-128
+            const uint64_t *const cur = inv ? sR : sO;
+            uint32_t nmemo = 0; // scored locations of this strand (wave-uniform)
             const uint32_t so = inv ? (patl - l) : 0u; // RestMatch::getMatchOffset, RestMatch.hpp:84-89
 #pragma unroll 1
             for (int la = 0; la < 6; ++la) {
@@ -282,7 +303,15 @@ __global__ __launch_bounds__(256) void match_wave_kernel(MatchArgs a)
                     const unsigned st = (unsigned)(info >> ST_SHIFT), er = (unsigned)(info >> ER_SHIFT) & 15;
                     if (st == (unsigned)(inv ? ST_REVERSE : ST_STRAIGHT) && er == 0) break;
                 }
-                const WaveRange R = wave_lookup(a, shi, slo, la);
+                WaveRange R; // (broadcast from the lane that looked it up)
+                {
+                    const int src = 6 * inv + la;
+                    const uint64_t e = (uint64_t)(uintptr_t)RL.E, w = (uint64_t)(uintptr_t)RL.row;
+                    R.E = (const uint2 *)(uintptr_t)(((uint64_t)(uint32_t)__shfl((int)(e >> 32), src) << 32) | (uint32_t)__shfl((int)e, src));
+                    R.row = (const uint32_t *)(uintptr_t)(((uint64_t)(uint32_t)__shfl((int)(w >> 32), src) << 32) | (uint32_t)__shfl((int)w, src));
+                    R.lo = (uint32_t)__shfl((int)RL.lo, src); R.cnt = (uint32_t)__shfl((int)RL.cnt, src); R.key = (uint32_t)__shfl((int)RL.key, src);
+                    R.mode = (uint32_t)__shfl((int)RL.mode, src); R.partner = (uint32_t)__shfl((int)RL.partner, src); R.counted = (uint32_t)__shfl((int)RL.counted, src);
+                }
                 if (lane == 0) { cL++; cP += R.cnt; cC += R.counted; }
                 const uint32_t xa = (0x940u >> (2 * la)) & 3u, xc = (0xfb9u >> (2 * la)) & 3u;
 #pragma unroll 1
@@ -314,7 +343,7 @@ __global__ __launch_bounds__(256) void match_wave_kernel(MatchArgs a)
                         }
                     }
                     // ---- seed window on the text, filters, Hamming distance: every lane for its own candidate
-                    bool hit = false;
+                    bool hit = false, scored = false;
                     uint32_t pos = 0, total = 0, frag = 0, first = 0;
                     float sc = 1.0f; // ComputeScore<...,false>, ComputeScore.hpp:31-45
                     if (cand) {
@@ -340,44 +369,29 @@ __global__ __launch_bounds__(256) void match_wave_kernel(MatchArgs a)
                             cV++;
                             ok = frag_valid(a.t, pos, patl, frag) && !(a.t.has_wild && !wild_free(a.t.wild, pos, patl));
                         }
-                        if (ok && lng) {
+                        if (ok) {
+                            // Hamming distance of the whole oriented read against text[pos, pos+patl)
+                            // = seedk + RestMatch::computeDistance (RestMatch.hpp:39-81)
                             total = long_distance(T, cur, pos, nw, lastmask, a.totalkmax);
                             if (total <= a.totalkmax) {
                                 hit = true;
                                 cH++; // one updater::update call per list, match.hpp:411
-                                if (SCORES)
-                                    sc = long_score(sLL, T, cur, pos, patl, !a.b.qual ? nullptr : (patl <= WV_QL ? (const uint8_t *)sQual[threadIdx.x >> 6] : a.b.qual + o0),
-                                                    (uint32_t)inv);
+                                if (SCORES && !memo_score(sMemoPos[threadIdx.x >> 6], sMemoSc[threadIdx.x >> 6], nmemo, pos, sc)) {
+                                    sc = long_score(sLL, T, cur, pos, patl, !a.b.qual ? nullptr : (q_lds ? (const uint8_t *)qst + 16 : a.b.qual + o0), (uint32_t)inv);
+                                    scored = true;
+                                }
                                 first = (z0 && z1) ? 0u : (z0 && z2) ? 1u : (z0 && z3) ? 2u : (z1 && z2) ? 3u : (z1 && z3) ? 4u : 5u;
                             }
-                        } else if (ok) {
-                            // Hamming distance of the whole oriented read against text[pos, pos+patl)
-                            // = seedk + RestMatch::computeDistance (RestMatch.hpp:39-81)
-                            const uint64_t wi = pos >> 5;
-                            const unsigned sh = 2u * (pos & 31);
-                            uint64_t tw[W], t[W + 2];
-#pragma unroll
-                            for (int j = 0; j <= W; j += 2) {
-                                U64x2 p2 = {0ull, 0ull};
-                                if ((uint32_t)j <= nw) p2 = load2(T + wi + j);
-                                t[j] = p2.a; t[j + 1] = p2.b;
-                            }
-#pragma unroll
-                            for (int j = 0; j < W; ++j) {
-                                const uint64_t al = sh ? ((t[j] << sh) | (t[j + 1] >> (64 - sh))) : t[j];
-                                tw[j] = al;
-                                const uint64_t x = al ^ O[j];
-                                uint64_t d = ((x >> 1) | x) & M55;
-                                if ((uint32_t)j + 1 == nw) d &= lastmask;
-                                if ((uint32_t)j < nw) total += __popcll(d);
-                            }
-                            if (total <= a.totalkmax) {
-                                hit = true;
-                                cH++; // one updater::update call per list, match.hpp:411
-                                if (SCORES)
-                                    sc = score_location<W>(sLL, O, tw, patl, GlobalRow{a.b.qual ? a.b.qual + o0 : nullptr}, a.b.qual != nullptr, (uint32_t)inv);
-                                first = (z0 && z1) ? 0u : (z0 && z2) ? 1u : (z0 && z3) ? 2u : (z1 && z2) ? 3u : (z1 && z3) ? 4u : 5u;
-                            }
+                        }
+                    }
+                    if (SCORES) { // the scores computed in this round are kept for the lists to come (the same window, the same score)
+                        const unsigned long long sm = __ballot(scored);
+                        if (sm) {
+                            const uint32_t slot = nmemo + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull));
+                            if (scored && slot < WV_MEMO) { sMemoPos[threadIdx.x >> 6][slot] = pos; sMemoSc[threadIdx.x >> 6][slot] = sc; }
+                            nmemo = min(WV_MEMO, nmemo + (uint32_t)__popcll(sm));
+                            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
                         }
                     }
                     // ---- the survivors, compacted by ballot, in entry order
@@ -430,11 +444,13 @@ void rh_launch_match_wave(real_hip_ctx *ctx, const MatchArgs &a, bool all)
     const uint64_t blocks = (waves + 3) / 4;
     dim3 grid((unsigned)(blocks < 2048 ? blocks : 2048)), block(256); // eight workgroups per CU
     const bool sc = ctx->prm.scores != 0;
-    if (all) {
-        if (sc) hipLaunchKernelGGL((match_wave_kernel<true, true>), grid, block, 0, ctx->stream, a);
-        else    hipLaunchKernelGGL((match_wave_kernel<false, true>), grid, block, 0, ctx->stream, a);
-    } else {
-        if (sc) hipLaunchKernelGGL((match_wave_kernel<true, false>), grid, block, 0, ctx->stream, a);
-        else    hipLaunchKernelGGL((match_wave_kernel<false, false>), grid, block, 0, ctx->stream, a);
-    }
+    const bool lng = a.b.maxpatl > 32u * RH_MAXW; // a read of the batch may be longer than the registers of a lane hold
+#define RH_WAVE_LAUNCH(S, A)                                                                                  \
+    do {                                                                                                      \
+        if (lng) hipLaunchKernelGGL((match_wave_kernel<S, A, true>), grid, block, 0, ctx->stream, a);         \
+        else     hipLaunchKernelGGL((match_wave_kernel<S, A, false>), grid, block, 0, ctx->stream, a);        \
+    } while (0)
+    if (all) { if (sc) RH_WAVE_LAUNCH(true, true); else RH_WAVE_LAUNCH(false, true); }
+    else     { if (sc) RH_WAVE_LAUNCH(true, false); else RH_WAVE_LAUNCH(false, false); }
+#undef RH_WAVE_LAUNCH
 }

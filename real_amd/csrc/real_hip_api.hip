@@ -445,6 +445,7 @@ struct Staged {
     const uint8_t *bases = nullptr, *qual = nullptr;
     const uint64_t *off = nullptr;
     uint32_t upatl = 0, maxpatl = 0, W = 0;
+    bool maxpatl_declared = false; // device offsets with the caller's bound: longer reads may exist (they get a wave each)
     uint32_t packed = 0;             // the matcher reads the 2-bit packed bases itself
     const uint8_t *nflags = nullptr;
 };
@@ -480,6 +481,7 @@ static int stage_batch(real_hip_ctx *ctx, const real_hip_batch &b, Staged &s, co
         if (b.on_device) {
             s.off = b.offsets;
             s.maxpatl = b.max_patl;
+            s.maxpatl_declared = b.max_patl != 0;
             if (!s.maxpatl && (rc = rh_max_patl(ctx, s.off, n, &s.maxpatl))) return rc;
         } else {
             for (uint64_t i = 0; i < n; ++i) {
@@ -548,7 +550,7 @@ static void fill_args(real_hip_ctx *ctx, const Staged &s, uint64_t n, MatchArgs 
     rh_index_geometry(l, pb, &a.ix.pshift, &a.ix.fshift, &a.ix.fbits, &a.ix.pbits);
     a.ix.fine = (uint32_t)ctx->fine;
     a.b.bases = s.bases; a.b.qual = ctx->prm.scores ? s.qual : nullptr; a.b.off = s.off;
-    a.b.n_reads = n; a.b.upatl = s.upatl; a.b.W = s.W;
+    a.b.n_reads = n; a.b.upatl = s.upatl; a.b.W = s.W; a.b.maxpatl = s.maxpatl_declared ? REAL_HIP_MAX_PATL_LONG : s.maxpatl;
     a.b.packed = s.packed; a.b.nflags = s.nflags;
     a.LL = (const double *)ctx->LL.p;
     a.counters = (unsigned long long *)ctx->counters.p;

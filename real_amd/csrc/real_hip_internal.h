@@ -89,6 +89,7 @@ struct DevBatch {
     uint32_t packed;
     const uint8_t *nflags;
     uint32_t fresh;        // matchUnique: the records are not read, every read of the batch starts as NoMatch / -FLT_MAX
+    uint32_t maxpatl;      // the longest read of the batch (declared or measured): beyond 32 * RH_MAXW the wave matcher keeps room for long reads
 };
 
 struct MatchArgs {
