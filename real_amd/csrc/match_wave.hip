@@ -4,8 +4,9 @@
 // (match.hpp:383-413 is a serial loop over the equal range).  A read that lands on a low-complexity signature
 // -- an equal range of 10^5..10^6 entries in a real genome -- would keep that lane, and with it its wave, busy
 // for 0.1..1 s.  Such reads (an equal range or bucket scan longer than BIG_T entries; more verified locations or
-// update() events than a lane can park) are handed over to this kernel instead.  Here the 64 lanes of a wave take
-// 64 entries of the equal range at a time:
+// update() events than a lane can park), and reads longer than a lane's registers hold, are handed over to this
+// kernel instead.  The read sits in the wave's LDS (words of 32 bases, both strands; its qualities), twelve lanes look
+// up its twelve equal ranges at once, and then the 64 lanes of the wave take 64 entries of an equal range at a time:
 //     entry -> partner filter (match.hpp:386 on the partner bits the entry carries) -> seed window on the text
 //           -> position / fragment / N checks (match.hpp:390-398) -> Hamming verify (RestMatch.hpp:39-81)
 //           -> score (ComputeScore.hpp:50-190), every lane for its own candidate;
@@ -120,7 +121,7 @@ __device__ __forceinline__ WaveRange wave_lookup(const MatchArgs &a, uint64_t sh
     return R;
 }
 
-// ---- reads longer than the registers hold (REAL_HIP_MAX_PATL < patl <= REAL_HIP_MAX_PATL_LONG) -----------------------
+// ---- the read as LDS words (any length up to REAL_HIP_MAX_PATL_LONG) ---------------------------------------------------
 // The read sits in the wave's LDS as words of 32 bases, straight and reverse-complemented; every lane walks the words of
 // its own candidate in run-time loops (an LDS word is the same address in all lanes: a broadcast).
 #define WV_NWL (REAL_HIP_MAX_PATL_LONG / 32u)
