@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--seg", type=int, default=1000)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--errprob", type=float, default=0.02)
+    ap.add_argument("--fragments", type=int, default=1, help="the genome as this many fragments (chromosomes, scaffolds)")
+    ap.add_argument("--n-runs", type=int, default=0, help="runs of 1000 N each")
     ap.add_argument("--table-kind", type=int, default=0)
     ap.add_argument("--prefix-bits", type=int, default=0)
     args = ap.parse_args()
@@ -42,17 +44,23 @@ def main():
         dst = (torch.randint(0, G - args.seg, (fam,), generator=g)).to(dev)
         sym[(dst[:, None] + ar[None, :]).reshape(-1)] = sym[(src[:, None] + ar[None, :]).reshape(-1)]
     m = HipMatcher(RealOptions(seedl=32, seedkmax=2, totalkmax=3, scores=True).normalise(), device=0, table_kind=args.table_kind, prefix_bits=args.prefix_bits)
-    m.set_text_symbols(0, sym, np.array([0, G], dtype=np.uint64))
+    if args.n_runs:
+        ns = torch.randint(0, G - 1000, (args.n_runs,), generator=g).to(dev)
+        sym[(ns[:, None] + ar[None, :1000]).reshape(-1)] = 4
+    cuts = np.unique(np.random.default_rng(5).integers(1000, G - 1000, size=max(args.fragments - 1, 0))) if args.fragments > 1 else np.zeros(0, dtype=np.int64)
+    frag = np.concatenate([[0], cuts, [G]]).astype(np.uint64)
+    m.set_text_symbols(0, sym, frag)
     m.build_index_block()
     bases, qual, _, _ = bench.gen_reads(torch, sym, n, patl, args.errprob, 4, dev)
     del sym
-    pk = bench.pack_bases(torch, bases, n, patl)
-    dt, ctr, (ms, ln), (rms, rn), (info, _) = bench.timed_unique(torch, None, m, rlib, pk, qual, patl, n, args.steps, 1, 1, 0, dev, dev, packed=True)
+    packed = not args.n_runs   # (reads that hold an N cannot be packed without their flags: bytes then)
+    pk = bench.pack_bases(torch, bases, n, patl) if packed else bases
+    dt, ctr, (ms, ln), (rms, rn), (info, _) = bench.timed_unique(torch, None, m, rlib, pk, qual, patl, n, args.steps, 1, 1, 0, dev, dev, packed=packed)
     st = (info >> 61) & 7
     print(json.dumps({"genome_mbp": args.genome_mbp, "reads": n, "share_in_repeats": args.share, "copies": args.copies,
                       "ms_per_step": dt / args.steps * 1e3, "reads_per_s": n * args.steps / dt,
                       "lane_kernel_ms": ms / max(ln, 1), "wave_kernel_ms": rms / max(rn, 1),
-                      "table_kind": m.table_kind, "prefix_bits": m.prefix_bits, "handed_over_frac": ctr["handed_over"] / max(ctr["reads"], 1),
+                      "table_kind": m.table_kind, "prefix_bits": m.prefix_bits, "fragments": args.fragments, "n_runs": args.n_runs, "handed_over_frac": ctr["handed_over"] / max(ctr["reads"], 1),
                       "nonunique_frac": float((st == 4).float().mean().item()), "unique_frac": float(((st == 1) | (st == 2)).float().mean().item())}))
 
 
