@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--seg", type=int, default=1000)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--errprob", type=float, default=0.02)
+    ap.add_argument("--at", type=float, default=0.5, help="share of A+T in the (i.i.d.) genome: 0.5 = uniform; 0.8 = an AT-rich genome with its uneven buckets")
     ap.add_argument("--fragments", type=int, default=1, help="the genome as this many fragments (chromosomes, scaffolds)")
     ap.add_argument("--n-runs", type=int, default=0, help="runs of 1000 N each")
     ap.add_argument("--table-kind", type=int, default=0)
@@ -36,6 +37,13 @@ def main():
     dev = torch.device("cuda", 0)
     G, n, patl = int(args.genome_mbp * 1e6), args.reads, 100
     sym = bench.gen_genome(torch, G, 3, dev)
+    if args.at != 0.5:           # A, T with probability at/2 each, C, G with (1 - at)/2 each
+        for lo in range(0, G, 1 << 28):
+            hi = min(G, lo + (1 << 28))
+            u = torch.rand(hi - lo, device=dev)
+            at = u < args.at
+            sym[lo:hi] = torch.where(at, torch.where(u < args.at / 2, 0, 3), torch.where(u < args.at + (1 - args.at) / 2, 1, 2)).to(torch.uint8)
+            del u, at
     fam = int(G * args.share / (args.copies * args.seg))
     g = torch.Generator(device="cpu"); g.manual_seed(7)
     ar = torch.arange(args.seg, device=dev)
@@ -43,6 +51,7 @@ def main():
     for c in range(args.copies - 1):           # every family: the source segment and copies - 1 exact copies elsewhere
         dst = (torch.randint(0, G - args.seg, (fam,), generator=g)).to(dev)
         sym[(dst[:, None] + ar[None, :]).reshape(-1)] = sym[(src[:, None] + ar[None, :]).reshape(-1)]
+    torch.cuda.synchronize(); torch.cuda.empty_cache()   # (the index wants the memory torch's allocator would keep)
     m = HipMatcher(RealOptions(seedl=32, seedkmax=2, totalkmax=3, scores=True).normalise(), device=0, table_kind=args.table_kind, prefix_bits=args.prefix_bits)
     if args.n_runs:
         ns = torch.randint(0, G - 1000, (args.n_runs,), generator=g).to(dev)
@@ -60,7 +69,7 @@ def main():
     print(json.dumps({"genome_mbp": args.genome_mbp, "reads": n, "share_in_repeats": args.share, "copies": args.copies,
                       "ms_per_step": dt / args.steps * 1e3, "reads_per_s": n * args.steps / dt,
                       "lane_kernel_ms": ms / max(ln, 1), "wave_kernel_ms": rms / max(rn, 1),
-                      "table_kind": m.table_kind, "prefix_bits": m.prefix_bits, "fragments": args.fragments, "n_runs": args.n_runs, "handed_over_frac": ctr["handed_over"] / max(ctr["reads"], 1),
+                      "table_kind": m.table_kind, "prefix_bits": m.prefix_bits, "at": args.at, "fragments": args.fragments, "n_runs": args.n_runs, "handed_over_frac": ctr["handed_over"] / max(ctr["reads"], 1),
                       "nonunique_frac": float((st == 4).float().mean().item()), "unique_frac": float(((st == 1) | (st == 2)).float().mean().item())}))
 
 
