@@ -372,6 +372,49 @@ def test_repeat_cliff_is_bit_exact_and_bounded_in_time(ora, seedl, kind, pb, sco
     m.close()
 
 
+@pytest.mark.parametrize("copies,kind", [(2, 3), (3, 3), (4, 3), (6, 3), (3, 2), (4, 0)])
+def test_reads_on_few_copy_repeats_stay_with_the_lane_matcher(ora, copies, kind):
+    """Exact copies of a 1 kbp segment (what a real genome is full of): every read on them has `copies` locations per
+    strand, each reached through up to six lists.  Records, scores and counters are the oracle's; and up to four copies
+    the reads are matched by the lane-per-read kernel -- a window is queued once, a parked location is recognised when it
+    comes again (match_kernel.hip: queue_push, process_loaded) -- instead of being handed to the wave matcher one by one."""
+    rng = np.random.default_rng(11 + copies)
+    G = 300_000
+    sym = rng.integers(0, 4, size=G, dtype=np.uint8)
+    src = 10_000
+    for c in range(copies - 1):
+        d = 40_000 + 35_000 * c
+        sym[d:d + 1000] = sym[src:src + 1000]
+    frag = np.array([0, G], dtype=np.uint64)
+    reads = []
+    for i in range(120):
+        r = sym[src + 50 + 7 * i: src + 150 + 7 * i].copy()
+        if i % 2:
+            r = synth.revcomp(r)
+        if i % 3 == 0:
+            r[(11 * i) % 100] = (r[(11 * i) % 100] + 1) & 3          # an error, in the seed or behind it
+        reads.append(r)
+    bases = np.concatenate(reads).astype(np.uint8)
+    qual = (rng.integers(5, 40, size=bases.shape[0])).astype(np.uint8)
+    offsets = np.arange(len(reads) + 1, dtype=np.uint64) * np.uint64(100)
+    p = ora.make_params(seedl=32, seedkmax=2, totalkmax=3, scores=1)
+    oinfo, oscore, octr = _oracle_unique(ora, None, sym, frag, 32, 0, p, bases, qual, offsets)
+    m = UniqueMatcher(_opts(32, 2, 3, 1), table_kind=kind, prefix_bits=14 if kind == 3 else (29 if kind == 2 else 0))
+    m.set_text_symbols(0, sym, frag)
+    m.build_index_block()
+    info, score = m.match_unique(bases, qual, patl=100)
+    _compare_unique(info, score, oinfo, oscore, 1)
+    c = m.counters()
+    for kk in ("reads", "lookups", "candidates", "seedpass", "hits"):
+        assert c[kk] == octr[kk], (kk, c[kk], octr[kk])
+    assert (unpack_info(info)[0] == 4).sum() >= 100           # NonUnique: the case is what it claims to be
+    if copies <= 4:
+        assert c["handed_over"] == 0, c
+    else:
+        assert c["handed_over"] > 0, c
+    m.close()
+
+
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 257, 1000])
 def test_batch_sizes_around_the_tile_of_64_reads(ora, n):
     """The waves of the resident grid take tiles of 64 reads from a counter: batches of less than a tile, of whole tiles
