@@ -193,10 +193,18 @@ __device__ __forceinline__ void flush_pending(const MatchArgs &a, LaneState<W, S
 // the windows were reached first, the canonical order of their first update() events; every later update() of a window
 // that has had one leaves the record as it is (kernel_common.h: fold_update; matchAll keeps the first one only), so the
 // record does not depend on where those are delivered.
-__device__ __forceinline__ void queue_push(uint32_t *q_pos, uint8_t *q_la, uint32_t &qn, uint32_t pos, int la)
+// `anywhere`: the window is looked for in the whole queue.  That needs entries whose being enumerated means being a member
+// of the list's equal range (32-bit signatures: the entry carries the whole signature) -- then a window's first entry IS its
+// first update(), if it has any.  With wider signatures an entry is enumerated on a prefix or fingerprint and may turn out
+// not to be a member (process_loaded): merged into such an earlier entry, the window's first real update() would be
+// delivered ahead of windows that were reached before it.  There only the last entry is merged with (a new entry would
+// take the same place).
+__device__ __forceinline__ void queue_push(uint32_t *q_pos, uint8_t *q_la, uint32_t &qn, uint32_t pos, int la, bool anywhere)
 {
-    for (uint32_t k = qn; k-- > 0;) // (from the last entry: that is where the true locus of the previous list is)
+    for (uint32_t k = qn; k-- > 0;) { // (from the last entry: that is where the true locus of the previous list is)
         if (q_pos[k * 64] == pos) { q_la[k * 64] |= (uint8_t)(1u << la); return; }
+        if (!anywhere) break;
+    }
     q_pos[qn * 64] = pos; q_la[qn * 64] = (uint8_t)(1u << la); qn++;
 }
 
@@ -436,7 +444,7 @@ __device__ __forceinline__ void scan_lists(const MatchArgs &a, LaneState<W, SCOR
                         const uint32_t x = (e.x & pmask) ^ rp;
                         keep = __popc(((x >> 1) | x) & 0x55555555u) <= a.seedkmax;
                     }
-                    if (keep) queue_push(q_pos, q_la, qn, e.y, LA0 + i);
+                    if (keep) queue_push(q_pos, q_la, qn, e.y, LA0 + i, pbits != 0);
                 }
                 j++;
             }
@@ -582,7 +590,7 @@ __device__ __forceinline__ void match_lists_fine(const MatchArgs &a, LaneState<W
                     // only be larger)
                     const uint32_t x = (e[u].x & pmask) ^ r;
                     if (fpk ? (e[u].x == r) : (__popc(((x >> 1) | x) & 0x55555555u) <= a.seedkmax)) {
-                        queue_push(q_pos, q_la, qn, e[u].y, LA0 + (int)li[u]);
+                        queue_push(q_pos, q_la, qn, e[u].y, LA0 + (int)li[u], !fpk);
                     }
                 }
             }
@@ -874,7 +882,7 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
             // known mismatches => rejected without touching the text (exact: the full count can only be larger)
             bool pass = step && (wide ? (x == 0u) : (__popc(((x >> 1) | x) & 0x55555555u) <= a.seedkmax));
             const bool merge = pass && qn && pos == q_last;
-            if (pass && !merge && qn >= 2) { // (repeats: a window that stands further up in the queue gets this list's bit there)
+            if (!wide && pass && !merge && qn >= 2) { // (repeats: a window that stands further up in the queue gets this list's bit there; see queue_push)
                 for (uint32_t k = 0; k + 1 < qn; ++k)
                     if (q_pos[k * 64] == pos) { q_la[k * 64] |= (uint8_t)(1u << la); pass = false; break; }
             }

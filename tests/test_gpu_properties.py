@@ -125,3 +125,18 @@ def test_ragged_max_length_and_edge_reads(ora):
         c = m.counters()
         assert all(c[k] == octr[k] for k in ("reads", "lookups", "candidates", "seedpass", "hits"))
         m.close()
+
+
+def test_fuzz_campaign_regressions():
+    """Configurations of bench_support/fuzz_parity.py (randomised parity campaign, seed 1) that once differed from the oracle:
+    64-bit signatures on a genome with repeats, bucket-start and fingerprint tables -- a window enumerated on a prefix /
+    fingerprint without being a member of that list's equal range must not give its queue position to a later, real
+    update() (match_kernel.hip: queue_push).  The campaign itself is open-ended and not part of the suite."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench_support", "fuzz_parity.py"), "--seed", "1", "--seconds", "600",
+                        "--only", "530", "568"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert "568 configurations, 0 differ" in p.stdout
