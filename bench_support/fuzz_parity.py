@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--only", type=int, nargs="*", default=[], help="run only these iterations of the seed (the others are generated and skipped) and say what differs")
     args = ap.parse_args()
+    import torch
+    torch.cuda.init()       # (before the library opens its own contexts: afterwards torch finds no device in this process)
     import oracle_lib as ora
     from real_amd import synth
     from real_amd.matcher import AllMatcher, RealOptions, UniqueMatcher
@@ -77,10 +79,40 @@ def main():
                 m = UniqueMatcher(opts, prefix_bits=pb, table_kind=kind)
                 m.set_text_symbols(0, g.sym, g.frag_start)
                 m.build_index_block()
+                variant = "host"
                 if ragged:
                     info, score = m.match_unique(b.bases, b.qual, b.offsets)
+                elif rng.random() < 0.4:
+                    # the same batch resident on the device: arrays at any byte address, bases packed where the batch allows
+                    # it (reads that hold an N are flagged), records written from scratch
+                    import torch
+                    variant = "device"
+                    nr = b.n_reads
+                    sh_b, sh_q = int(rng.integers(0, 16)), int(rng.integers(0, 16))
+                    pack = (nr * patl) % 4 == 0 and rng.random() < 0.6
+                    big_q = torch.zeros(nr * patl + 64, dtype=torch.uint8, device="cuda")
+                    dq = big_q[sh_q:sh_q + nr * patl]; dq.copy_(torch.from_numpy(b.qual))
+                    nfl = None
+                    if pack:
+                        variant = "device, packed"
+                        q4 = np.minimum(b.bases, 3).reshape(-1, 4)
+                        pk = ((q4[:, 0] << 6) | (q4[:, 1] << 4) | (q4[:, 2] << 2) | q4[:, 3]).astype(np.uint8)
+                        flags = np.zeros((nr + 7) // 8, dtype=np.uint8)
+                        badr = np.nonzero((b.bases.reshape(nr, patl) > 3).any(axis=1))[0]
+                        np.bitwise_or.at(flags, badr // 8, (1 << (badr % 8)).astype(np.uint8))
+                        big_b = torch.zeros(pk.shape[0] + 64, dtype=torch.uint8, device="cuda")
+                        db = big_b[sh_b:sh_b + pk.shape[0]]; db.copy_(torch.from_numpy(pk))
+                        nfl = torch.from_numpy(flags).cuda()
+                    else:
+                        big_b = torch.zeros(nr * patl + 64, dtype=torch.uint8, device="cuda")
+                        db = big_b[sh_b:sh_b + nr * patl]; db.copy_(torch.from_numpy(b.bases))
+                    di = torch.full((nr,), 0x7123456789abcdef, dtype=torch.int64, device="cuda")
+                    ds = torch.full((nr,), 1e30, dtype=torch.float32, device="cuda")
+                    m.match_unique(db, dq, patl=patl, info=di, score=ds, n_reads=nr, packed=pack, nflags=nfl, fresh=True)
+                    info, score = di.cpu().numpy().view(np.uint64), ds.cpu().numpy()
                 else:
                     info, score = m.match_unique(b.bases, b.qual, patl=patl)
+                desc["variant"] = variant
                 c = m.counters()
                 ok = np.array_equal(info, oinfo) and (not scores or np.array_equal(score.view(np.uint32), oscore.view(np.uint32)))
                 ok = ok and all(c[kk] == octr[kk] for kk in ("reads", "lookups", "candidates", "seedpass", "hits"))
