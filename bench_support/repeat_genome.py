@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--seg", type=int, default=1000)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--errprob", type=float, default=0.02)
+    ap.add_argument("--check", type=int, default=0, help="compare this many reads of the step (strided) with the CPU port of the oracle on the same genome and index")
     ap.add_argument("--at", type=float, default=0.5, help="share of A+T in the (i.i.d.) genome: 0.5 = uniform; 0.8 = an AT-rich genome with its uneven buckets")
     ap.add_argument("--fragments", type=int, default=1, help="the genome as this many fragments (chromosomes, scaffolds)")
     ap.add_argument("--n-runs", type=int, default=0, help="runs of 1000 N each")
@@ -61,15 +62,25 @@ def main():
     m.set_text_symbols(0, sym, frag)
     m.build_index_block()
     bases, qual, _, _ = bench.gen_reads(torch, sym, n, patl, args.errprob, 4, dev)
+    sym_host = sym.cpu().numpy() if args.check else None
     del sym
     packed = not args.n_runs   # (reads that hold an N cannot be packed without their flags: bytes then)
     pk = bench.pack_bases(torch, bases, n, patl) if packed else bases
-    dt, ctr, (ms, ln), (rms, rn), (info, _) = bench.timed_unique(torch, None, m, rlib, pk, qual, patl, n, args.steps, 1, 1, 0, dev, dev, packed=packed)
+    dt, ctr, (ms, ln), (rms, rn), (info, score) = bench.timed_unique(torch, None, m, rlib, pk, qual, patl, n, args.steps, 1, 1, 0, dev, dev, packed=packed)
     st = (info >> 61) & 7
+    parity = None
+    if args.check:          # the oracle's CPU port on the same genome and the same index (the six lists downloaded from the device)
+        opts = RealOptions(seedl=32, seedkmax=2, totalkmax=3, scores=True).normalise()
+        cpu = bench.CpuSide(m, sym_host, frag, opts, 16)
+        b, q, off, stride, k1 = bench.strided_sample(torch, bases, qual, n, patl, args.check)
+        oinfo, oscore, _ = cpu.ora.match_unique(cpu.og, cpu.ix, cpu.params(opts), b, q, off)
+        gi = info[::stride][:k1].contiguous().cpu().numpy().view(np.uint64)
+        gs = score[::stride][:k1].contiguous().cpu().numpy()
+        parity = bool(np.array_equal(gi, oinfo) and np.array_equal(gs.view(np.uint32), oscore.view(np.uint32)))
     print(json.dumps({"genome_mbp": args.genome_mbp, "reads": n, "share_in_repeats": args.share, "copies": args.copies,
                       "ms_per_step": dt / args.steps * 1e3, "reads_per_s": n * args.steps / dt,
                       "lane_kernel_ms": ms / max(ln, 1), "wave_kernel_ms": rms / max(rn, 1),
-                      "table_kind": m.table_kind, "prefix_bits": m.prefix_bits, "at": args.at, "fragments": args.fragments, "n_runs": args.n_runs, "handed_over_frac": ctr["handed_over"] / max(ctr["reads"], 1),
+                      "table_kind": m.table_kind, "prefix_bits": m.prefix_bits, "at": args.at, "fragments": args.fragments, "n_runs": args.n_runs, "parity_with_cpu_port": parity, "checked_reads": args.check, "handed_over_frac": ctr["handed_over"] / max(ctr["reads"], 1),
                       "nonunique_frac": float((st == 4).float().mean().item()), "unique_frac": float(((st == 1) | (st == 2)).float().mean().item())}))
 
 
