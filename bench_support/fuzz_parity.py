@@ -22,6 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=300)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--copy-prob", type=float, default=0.3, help="share of the configurations whose genome holds exact copies of a segment")
     ap.add_argument("--only", type=int, nargs="*", default=[], help="run only these iterations of the seed (the others are generated and skipped) and say what differs")
     args = ap.parse_args()
     import torch
@@ -45,7 +46,7 @@ def main():
         repeats = int(rng.choice([0, 5, 40]))
         g = synth.random_genome(n, seed=int(rng.integers(1 << 30)), n_frag=int(rng.choice([1, 2, 7])), n_runs=int(rng.choice([0, 3, 20])),
                                 repeats=repeats, repeat_len=int(rng.choice([150, 400, 1200])))
-        if rng.random() < 0.3:          # exact copies of a segment: reads on them have several locations
+        if rng.random() < args.copy_prob:  # exact copies of a segment: reads on them have several locations
             L = int(min(rng.choice([300, 1000]), n // 8))
             src = int(rng.integers(0, n - L))
             for _ in range(int(rng.integers(1, 7))):
