@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity campaign: many small random configurations (seed length, read length, mismatch bounds, scores, table
-kind, genomes with repeats / N runs / fragments / skewed composition, ragged and uniform batches, packed and byte bases,
+kind, genomes with repeats / N runs / fragments / skewed composition, reads with planted near-copies that differ from them in
+different seed segments (scores on: the order of the update() calls decides the record), ragged and uniform batches, packed and byte bases,
 matchUnique and matchAll), the HIP path through the C ABI against the oracle.  Not part of the test suite (run time is
 open-ended); prints every configuration that differs and exits 1 if any did.
 
@@ -23,6 +24,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=300)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--copy-prob", type=float, default=0.3, help="share of the configurations whose genome holds exact copies of a segment")
+    ap.add_argument("--diverged-prob", type=float, default=0.3, help="share of the uniform-length configurations whose reads have planted near-copies "
+                    "(1-2 substitutions in chosen seed segments, low qualities there): the class on which the order of the update() calls decides")
     ap.add_argument("--only", type=int, nargs="*", default=[], help="run only these iterations of the seed (the others are generated and skipped) and say what differs")
     args = ap.parse_args()
     import torch
@@ -54,10 +57,14 @@ def main():
                 g.sym[d:d + L] = g.sym[src:src + L]
         nreads = int(rng.choice([64, 257, 1500]))
         ragged = rng.random() < 0.3
+        diverged = False
         if ragged:
             parts = [synth.sample_reads(g, max(1, nreads // 3), int(rng.integers(max(4, seedl - 3), patl + 1)), 0.02, seed=int(rng.integers(1 << 30)),
                                         n_read_prob=0.001) for _ in range(3)]
             b = synth.concat_batches(parts)
+        elif rng.random() < args.diverged_prob and g.n >= 4 * nreads * (patl + 8):
+            b = synth.diverged_copy_reads(g, nreads, patl, seedl, seed=int(rng.integers(1 << 30)), q_max=int(rng.choice([40, 40, 63])))
+            diverged = True
         else:
             b = synth.sample_reads(g, nreads, patl, float(rng.choice([0.0, 0.02, 0.05])), seed=int(rng.integers(1 << 30)), n_read_prob=0.001)
         kind = int(rng.choice([0, 0, 2, 3, 3]))
@@ -69,7 +76,7 @@ def main():
         if args.only and it not in args.only:
             rng.random()  # (the mode draw below)
             continue
-        desc = dict(it=it, seedl=seedl, patl=patl, k=k, seedk=seedk, scores=scores, n=g.n, reads=b.n_reads, ragged=bool(ragged), kind=kind, pb=pb, repeats=repeats)
+        desc = dict(it=it, seedl=seedl, patl=patl, k=k, seedk=seedk, scores=scores, n=g.n, reads=b.n_reads, ragged=bool(ragged), kind=kind, pb=pb, repeats=repeats, diverged=diverged)
         try:
             opts = RealOptions(seedl=seedl, seedkmax=seedk, totalkmax=min(k, 15), scores=bool(scores), filter_level=2).normalise()
             p = ora.make_params(seedl=seedl, seedkmax=seedk, totalkmax=min(k, 15), scores=scores)

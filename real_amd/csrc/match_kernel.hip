@@ -69,8 +69,8 @@ static_assert(BKX_OFF + 256u <= stg_bytes(4, 3) && ROWBUF_OFF % 16 == 0 && QUEUE
 #ifndef RH_KEEP_TW_MAXW
 #define RH_KEEP_TW_MAXW 4
 #endif
-#define NPEND 4      // verified locations a lane parks until their scores are computed (flush_pending)
-#define PEND_EV 32   // update() events parked with them
+#define NPEND 4      // verified locations a lane parks until their scores are computed (flush_pending), each with the
+                     // set of lists through which it was reached (= its update() events)
 #define SLOT_NONE 7u
 #define PEND_OVF 0xffu // p_n of a read that is handed over to the wave-cooperative matcher (match_wave.hip)
 #define BIG_T 48u      // an equal range / bucket scan longer than this many entries is not walked by one lane: hand-over
@@ -102,8 +102,8 @@ struct LaneState {
     uint32_t p_pos[NPEND], p_meta[NPEND]; // text position; k | strand << 8 | fragment << 16
     uint64_t p_tw[W <= RH_KEEP_TW_MAXW ? W : 1]; // aligned text words of pending location 0 (kept for reads of up to 128 bases;
                                           // longer ones read the text again when they score: the registers are worth more)
-    uint32_t p_n, p_nev, cslot;           // locations, events, slot of the memo
-    uint64_t p_ev;                        // 2 bits per event: its location
+    uint32_t p_n, cslot;                  // locations, slot of the memo
+    uint32_t p_lm;                        // 6 bits per location: the lists whose update() call it has had (bit 6 j + la)
     uint32_t nhit; // matchAll: hits appended for this read
     // work counters of this read, packed (a register each would cost six of the 168): cA = L:4 | V:12 | S:12, cB = P:11 | C:11 | H:10.
     // No field overflows without the read being handed over -- a lane walks at most BIG_T entries of each of its 12 equal
@@ -134,12 +134,20 @@ __device__ __forceinline__ void deliver(const MatchArgs &a, LaneState<W, SCORES,
     }
 }
 
-// Scores of the parked locations, then their update() events in the order they occurred.  The score is
+// Scores of the parked locations, then their update() events in the reference's order.  The score is
 // ~1000 instructions of which every lane of a wave needs one or two per read, but at different points
 // of its candidate loop: computed where the hit is found, the wave would run that code once per
 // distinct point (5-6 times per wave, mostly idle lanes).  Parked, the lanes score together at the end
-// of the read; the fold sees the same events in the same order.  A read that needs more slots
-// (repeat-rich) is handed to the repeat kernel, which scores in place.
+// of the read.  A read that needs more slots (repeat-rich) is handed to the repeat kernel, which scores in place.
+//
+// Order of the events (the fold is order dependent when scores are on).  The reference calls ::match once
+// per strand and list (matchUniqueImplementation.cpp:407-497) and walks the equal range of that list in entry order =
+// ascending position (match.hpp:383-413): its update() calls are the triples (strand, list, position) that pass, in
+// lexicographic order.  A parked location carries the set of lists through which it passed, so that sequence is rebuilt
+// here from the sets alone, whatever the order in which the queue was filled and drained (a window reached again through
+// a later list, after other windows, has its later events at their own lists' turns -- not at its first one's).
+// Two consecutive update() calls for the same location are one: the second finds the record either at that location
+// (nothing differs), NonUnique with the same score comparison that just failed, or as untouched as the first left it.
 template <int W, bool SCORES, bool ALL, class Row>
 __device__ __forceinline__ void flush_pending(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL, const Row &qrow)
 {
@@ -176,9 +184,47 @@ __device__ __forceinline__ void flush_pending(const MatchArgs &a, LaneState<W, S
         const float v = score_location<W>(sLL, Ow, tw, s.patl, qrow, a.b.qual != nullptr, inv);
         if (j == 0) sc0 = v; else if (j == 1) sc1 = v; else if (j == 2) sc2 = v; else sc3 = v;
     }
+    // the event sequence: 2 bits per event = its location
+    uint64_t ev = 0;
+    uint32_t nev = 0;
+    if (s.p_n == 1) {
+        nev = (s.p_lm & 63u) ? 1u : 0u; // (all events of the read are this location's: one call)
+    } else if (ALL) {
+        // matchAll keeps one hit per location (process_loaded); unifyMatches orders them afterwards (rh_all_finish)
+#pragma unroll
+        for (uint32_t j = 0; j < NPEND; ++j)
+            if (j < s.p_n && ((s.p_lm >> (6 * j)) & 63u)) { ev |= (uint64_t)j << (2 * nev); nev++; }
+    } else if (s.p_n >= 2) {
+        // rank of every location by (strand, position); ord = the locations in that order, 2 bits each
+        uint32_t ord = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < NPEND; ++j) {
+            const uint64_t kj = ((uint64_t)((s.p_meta[j] >> 8) & 1u) << 32) | s.p_pos[j];
+            uint32_t rank = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < NPEND; ++i) {
+                const uint64_t ki = ((uint64_t)((s.p_meta[i] >> 8) & 1u) << 32) | s.p_pos[i];
+                if (i != j && i < s.p_n && (ki < kj || (ki == kj && i < j))) rank++;
+            }
+            if (j < s.p_n) ord |= j << (2 * rank);
+        }
+        const uint32_t strands = ((s.p_meta[0] >> 8) & 1u) | (((s.p_meta[1] >> 8) & 1u) << 1) | (((s.p_meta[2] >> 8) & 1u) << 2) | (((s.p_meta[3] >> 8) & 1u) << 3);
+        uint32_t last = SLOT_NONE;
 #pragma unroll 1
-    for (uint32_t e = 0; e < s.p_nev; ++e) {
-        const uint32_t j = (uint32_t)(s.p_ev >> (2 * e)) & 3u;
+        for (uint32_t sl = 0; sl < 12; ++sl) { // strand, list
+            const uint32_t inv = sl >= 6 ? 1u : 0u, la = sl - 6 * inv;
+#pragma unroll
+            for (uint32_t rk = 0; rk < NPEND; ++rk) {
+                const uint32_t j = (ord >> (2 * rk)) & 3u;
+                if (rk < s.p_n && ((strands >> j) & 1u) == inv && ((s.p_lm >> (6 * j + la)) & 1u) && j != last) {
+                    ev |= (uint64_t)j << (2 * nev); nev++; last = j;
+                }
+            }
+        }
+    }
+#pragma unroll 1
+    for (uint32_t e = 0; e < nev; ++e) {
+        const uint32_t j = (uint32_t)(ev >> (2 * e)) & 3u;
         deliver<W, SCORES, ALL>(a, s, j == 0 ? s.p_pos[0] : j == 1 ? s.p_pos[1] : j == 2 ? s.p_pos[2] : s.p_pos[3],
                                 j == 0 ? s.p_meta[0] : j == 1 ? s.p_meta[1] : j == 2 ? s.p_meta[2] : s.p_meta[3],
                                 j == 0 ? sc0 : j == 1 ? sc1 : j == 2 ? sc2 : sc3);
@@ -189,16 +235,17 @@ __device__ __forceinline__ void flush_pending(const MatchArgs &a, LaneState<W, S
 // of ::match (match.hpp:383-413)
 // A survivor of the partner filter goes to the lane's queue.  A window that is in the queue already -- the true locus is
 // found through 4.4 lists per read, the copies of a repeat through as many each -- only gets that list's bit set in its
-// entry: the drain then runs once per window instead of once per (window, list).  The entries stand in the order in which
-// the windows were reached first, the canonical order of their first update() events; every later update() of a window
-// that has had one leaves the record as it is (kernel_common.h: fold_update; matchAll keeps the first one only), so the
-// record does not depend on where those are delivered.
-// `anywhere`: the window is looked for in the whole queue.  That needs entries whose being enumerated means being a member
-// of the list's equal range (32-bit signatures: the entry carries the whole signature) -- then a window's first entry IS its
-// first update(), if it has any.  With wider signatures an entry is enumerated on a prefix or fingerprint and may turn out
-// not to be a member (process_loaded): merged into such an earlier entry, the window's first real update() would be
-// delivered ahead of windows that were reached before it.  There only the last entry is merged with (a new entry would
-// take the same place).
+// entry: the drain then runs once per window instead of once per (window, list).
+// `anywhere`: the window is looked for in the whole queue, not only in its last entry.  The order in which the fold sees
+// the update() calls does not depend on the queue when they are parked (scores on, matchAll): flush_pending rebuilds the
+// reference's order from the parked lists.  Without scores they are delivered as the queue is drained, the fold's result
+// is order-free but for the position bits a NonUnique record keeps (those of the first hit at its error level), and the
+// queue must hold the windows in the order of their first update(): with entries whose being enumerated means being a
+// member of the list's equal range (32-bit signatures: the entry carries the whole signature) a window's first entry IS
+// its first update(), if it has any, and it may be merged anywhere; with wider signatures an entry is enumerated on a
+// prefix or fingerprint and may turn out not to be a member (process_loaded) -- merged into such an earlier entry, the
+// window's first real update() would come ahead of windows that were reached before it -- so there only the last entry
+// is merged with (a new entry would take the same place).
 __device__ __forceinline__ void queue_push(uint32_t *q_pos, uint8_t *q_la, uint32_t &qn, uint32_t pos, int la, bool anywhere)
 {
     for (uint32_t k = qn; k-- > 0;) { // (from the last entry: that is where the true locus of the previous list is)
@@ -343,10 +390,8 @@ __device__ __forceinline__ void process_loaded(const MatchArgs &a, LaneState<W, 
         for (uint32_t e = 0; e < ne; ++e) deliver<W, SCORES, ALL>(a, s, s.cpos, meta, s.cscore);
         return;
     }
-    // park the events (they all refer to the memo's slot); out of room => the read is handed over
-    if (s.p_nev + ne > PEND_EV) { s.p_n = PEND_OVF; return; }
-    s.p_ev |= (((uint64_t)s.cslot * 0x5555555555555555ull) & (ne >= 32 ? ~0ull : ((1ull << (2 * ne)) - 1ull))) << (2 * s.p_nev);
-    s.p_nev += ne;
+    // park the events: the lists of this location's update() calls (flush_pending puts them in order)
+    s.p_lm |= events << (6 * s.cslot);
 }
 
 template <int W, bool SCORES, bool ALL, bool DEFER>
@@ -444,7 +489,7 @@ __device__ __forceinline__ void scan_lists(const MatchArgs &a, LaneState<W, SCOR
                         const uint32_t x = (e.x & pmask) ^ rp;
                         keep = __popc(((x >> 1) | x) & 0x55555555u) <= a.seedkmax;
                     }
-                    if (keep) queue_push(q_pos, q_la, qn, e.y, LA0 + i, pbits != 0);
+                    if (keep) queue_push(q_pos, q_la, qn, e.y, LA0 + i, pbits != 0 || SCORES || ALL);
                 }
                 j++;
             }
@@ -590,7 +635,7 @@ __device__ __forceinline__ void match_lists_fine(const MatchArgs &a, LaneState<W
                     // only be larger)
                     const uint32_t x = (e[u].x & pmask) ^ r;
                     if (fpk ? (e[u].x == r) : (__popc(((x >> 1) | x) & 0x55555555u) <= a.seedkmax)) {
-                        queue_push(q_pos, q_la, qn, e[u].y, LA0 + (int)li[u], !fpk);
+                        queue_push(q_pos, q_la, qn, e[u].y, LA0 + (int)li[u], !fpk || DEFER);
                     }
                 }
             }
@@ -882,7 +927,7 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
             // known mismatches => rejected without touching the text (exact: the full count can only be larger)
             bool pass = step && (wide ? (x == 0u) : (__popc(((x >> 1) | x) & 0x55555555u) <= a.seedkmax));
             const bool merge = pass && qn && pos == q_last;
-            if (!wide && pass && !merge && qn >= 2) { // (repeats: a window that stands further up in the queue gets this list's bit there; see queue_push)
+            if ((!wide || DEFER) && pass && !merge && qn >= 2) { // (repeats: a window that stands further up in the queue gets this list's bit there; see queue_push)
                 for (uint32_t k = 0; k + 1 < qn; ++k)
                     if (q_pos[k * 64] == pos) { q_la[k * 64] |= (uint8_t)(1u << la); pass = false; break; }
             }
@@ -928,7 +973,9 @@ template <int W, bool SCORES, bool ALL, bool DEFER, bool WIDE>
 __device__ __forceinline__ void match_read_rows(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL, uint8_t *stg, bool act)
 {
     const uint32_t patl = act ? s.patl : 32u * W;
-    s.p_n = s.p_nev = s.p_ev = 0; s.cslot = SLOT_NONE;
+    s.p_n = s.p_lm = 0; s.cslot = SLOT_NONE;
+#pragma unroll
+    for (int j = 0; j < NPEND; ++j) { s.p_pos[j] = 0; s.p_meta[j] = 0; }
     uint64_t rhi = 0, rlo = 0;
     if (act) seed_halves<W>(s.O, a.l, s.shi, s.slo, rhi, rlo);
     else { s.shi = s.slo = 0; }
@@ -963,7 +1010,9 @@ __device__ __forceinline__ void match_read(const MatchArgs &a, LaneState<W, SCOR
                                            uint8_t *q_la)
 {
     const uint32_t patl = s.patl;
-    s.p_n = s.p_nev = s.p_ev = 0; s.cslot = SLOT_NONE;
+    s.p_n = s.p_lm = 0; s.cslot = SLOT_NONE;
+#pragma unroll
+    for (int j = 0; j < NPEND; ++j) { s.p_pos[j] = 0; s.p_meta[j] = 0; }
     uint64_t rhi, rlo;
     seed_halves<W>(s.O, a.l, s.shi, s.slo, rhi, rlo);
     for (int inv = 0; inv < 2; ++inv) {
@@ -994,7 +1043,7 @@ __device__ __forceinline__ void match_read(const MatchArgs &a, LaneState<W, SCOR
 // The matcher proper: lane i of the grid takes read i of the batch.  A wave reads the bases of its 64 reads -- one
 // contiguous byte range of the caller's array -- through LDS, every lane packs its own read into registers, matches
 // both strands, and parks its hits (DEFER: scores on, or matchAll); then the wave reads the qualities of its reads the
-// same way and the lanes score and deliver together.  A read that needs more than NPEND locations / PEND_EV events,
+// same way and the lanes score and deliver together.  A read that needs more than NPEND locations,
 // or meets an equal range of more than BIG_T entries, is left untouched and its index appended to a.ovf_list: the
 // wave-cooperative matcher (match_wave.hip) does it all and counts it.
 // TK = kind of the bucket tables: 0 bucket starts, 1 directory entries (digests / fingerprints), 3 bucket rows,

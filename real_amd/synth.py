@@ -127,6 +127,73 @@ def sample_reads(g: Genome, n_reads: int, patl: int, errprob: float, seed: int,
                      true_pos=pos.astype(np.uint64), true_inv=inv)
 
 
+def near_copy_case(n: int = 300_000, seed: int = 5, patl: int = 100, seedl: int = 32):
+    """One read R with three planted near-copies X, A, C: X differs from R outside the seed, A in seed segment 2, C in seed
+    segment 1 (segments of seedl/4 bases), with qualities that give score(X) < score(A) < score(C), each step smaller
+    than epsilon = 3/70 * patl but X -> C larger.  The reference reaches them list by list (l0: X A | l1: X C | l2: X A C |
+    l3: X | l4: X A | l5: X C; matchUniqueImplementation.cpp:407-497, match.hpp:383-413): X is taken, A turns the record
+    NonUnique, C is taken, the A of list 2 turns it NonUnique for good.  Delivering all events of a window at the window's
+    first turn (X*6, A*3, C*3) ends Straight at C instead -- the case VERDICT r2 constructed."""
+    rng = np.random.default_rng(seed)
+    sym = rng.integers(0, 4, size=n, dtype=np.uint8)
+    R = rng.integers(0, 4, size=patl, dtype=np.uint8)
+    seg = seedl // 4
+    jx, ja, jc = seedl + (patl - seedl) // 2, 2 * seg + seg // 4, seg + seg // 4
+    for at, j in ((n // 30, jx), (2 * (n // 30), ja), (3 * (n // 30), jc)):
+        c = R.copy()
+        c[j] = (c[j] + 1) & 3
+        sym[at:at + patl] = c
+    q = np.full(patl, 35, dtype=np.uint8)
+    q[jx], q[ja], q[jc] = 6, 3, 1
+    g = Genome(sym=sym, frag_start=np.array([0, n], dtype=np.uint64), frag_names=[" random_%d" % n])
+    b = ReadBatch(bases=R.copy(), qual=q, offsets=np.array([0, patl], dtype=np.uint64), ids=["xac"])
+    return g, b, 3 * (n // 30)
+
+
+def diverged_copy_reads(g: Genome, n_reads: int, patl: int, seedl: int, seed: int, max_copies: int = 4,
+                        max_subst: int = 2, q_max: int = 40) -> ReadBatch:
+    """Reads with several near-copies in the genome (planted into ``g.sym`` in place): for each read a random word R,
+    2..max_copies copies of it at random places, on either strand, each with 0..max_subst substitutions at random bases
+    -- inside a chosen seed segment or behind the seed --, and random qualities 0..q_max for the read.  Copies of one read
+    differ in WHERE they differ from it, so they are members of different lists' equal ranges and score differently:
+    the class of input on which the order of the update() calls decides the record (scores on)."""
+    rng = np.random.default_rng(seed)
+    n = g.n
+    slot = patl + 8
+    n_slots = n // slot
+    want = n_reads * max_copies
+    assert n_slots >= want, "genome too small for the planted copies"
+    slots = rng.permutation(n_slots)[:want].reshape(n_reads, max_copies)
+    bases = np.empty((n_reads, patl), dtype=np.uint8)
+    qual = rng.integers(0, q_max + 1, size=(n_reads, patl)).astype(np.uint8)
+    seg = max(1, seedl // 4)
+    for i in range(n_reads):
+        R = rng.integers(0, 4, size=patl, dtype=np.uint8)
+        # the read itself: as it is, or reverse-complemented (then the seed of the oriented read is the copy's tail)
+        flip = rng.random() < 0.5
+        bases[i] = revcomp(R) if flip else R
+        for c in range(int(rng.integers(2, max_copies + 1))):
+            cp = R.copy()
+            for _ in range(int(rng.choice([0, 1, 1, 1, 2][:max_subst + 3]))):
+                where = int(rng.integers(0, 10))
+                if where < 4:
+                    j = where * seg + int(rng.integers(0, seg))              # seed segment of the straight read
+                elif where < 8:
+                    j = patl - 1 - ((where - 4) * seg + int(rng.integers(0, seg)))    # ... of the reversed one
+                else:
+                    j = int(rng.integers(0, patl))
+                j = min(j, patl - 1)
+                cp[j] = (cp[j] + 1 + rng.integers(0, 3)) & 3
+                if rng.random() < 0.8:
+                    # a low quality where the copy differs: its score lies a fraction of epsilon below the exact copy's
+                    qual[i, patl - 1 - j if flip else j] = rng.integers(0, 11)
+            at = int(slots[i, c]) * slot
+            g.sym[at:at + patl] = cp if rng.random() < 0.7 else revcomp(cp)
+    offsets = np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(patl)
+    return ReadBatch(bases=bases.reshape(-1).copy(), qual=qual.reshape(-1).copy(), offsets=offsets,
+                     ids=["d%d" % i for i in range(n_reads)])
+
+
 def concat_batches(batches: Sequence[ReadBatch]) -> ReadBatch:
     """Ragged batch from several uniform-length ones."""
     bases = np.concatenate([b.bases for b in batches])

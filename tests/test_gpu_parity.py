@@ -528,3 +528,83 @@ def test_repeat_cliff_match_all(ora, seedl, kind, pb):
     assert dt < 1.0, "repeat-rich reads took %.3f s (lane-per-read kernel %.1f ms, wave-per-read kernel %.1f ms, ordering pass %.1f ms)" % (
         dt, m.kernel_time(1)[0], m.kernel_time(4)[0], m.kernel_time(2)[0])
     m.close()
+
+
+@pytest.mark.parametrize("seedl,kind,pb", [(32, 0, 0), (32, 2, 29), (32, 3, 14), (16, 3, 13), (16, 2, 13), (16, 0, 0)])
+def test_near_copies_reach_the_fold_in_the_reference_order(ora, seedl, kind, pb):
+    """VERDICT r2 'weak' 1.  Scores on: three near-copies X, A, C of one read whose scores lie an epsilon-step apart, found
+    through different lists (synth.near_copy_case).  The reference calls update() list by list
+    (matchUniqueImplementation.cpp:407-497, match.hpp:383-413): X, A | X, C | X, A, C | ... and ends NonUnique; a matcher that
+    delivers all events of a window at the window's first turn ends Straight at C.  The lane matcher queues a window once
+    and must still deliver its events in the reference's order -- and must not dodge the case by handing the read over."""
+    g, b, pos_c = synth.near_copy_case(seedl=seedl)
+    p = ora.make_params(seedl=seedl, seedkmax=2, totalkmax=3, scores=1)
+    oinfo, oscore, octr = _oracle_unique(ora, None, g.sym, g.frag_start, seedl, 0, p, b.bases, b.qual, b.offsets)
+    st, fr, er, fi, po = unpack_info(oinfo)
+    assert (int(st[0]), int(po[0])) == (4, pos_c), "the case is what it claims to be: NonUnique in the reference's order"
+    m = UniqueMatcher(_opts(seedl, 2, 3, 1), prefix_bits=pb, table_kind=kind)
+    m.set_text_symbols(0, g.sym, g.frag_start)
+    m.build_index_block()
+    # the read alone, and as every lane of two tiles (both strands: the reverse complement finds the same three windows)
+    for reps in (1, 128):
+        bases = np.concatenate([b.bases if i % 2 == 0 else synth.revcomp(b.bases) for i in range(reps)])
+        qual = np.concatenate([b.qual if i % 2 == 0 else b.qual[::-1] for i in range(reps)])
+        m.counters(reset=True)
+        info, score = m.match_unique(bases, qual, patl=100)
+        c = m.counters()
+        assert c["handed_over"] == 0, c
+        for i in range(reps):
+            s_, f_, e_, fi_, p_ = unpack_info(info[i:i + 1])
+            assert int(s_[0]) == 4 and int(e_[0]) == 1, "read %d: state %d (reference: NonUnique)" % (i, int(s_[0]))
+            assert np.float32(score[i]).view(np.uint32) == oscore.view(np.uint32)[0]
+        assert info[0] == oinfo[0]
+    m.close()
+
+
+def _grouped_delivery_differs(ora, ev, oinfo, oscore, eps):
+    """number of reads whose record differs when every window's update() events are delivered at the window's first turn"""
+    import ctypes as C
+    n = oinfo.shape[0]
+    evs = ev[np.argsort(ev["read"], kind="stable")]
+    bounds = np.searchsorted(evs["read"], np.arange(n + 1))
+    nd = 0
+    for r in range(n):
+        seen = {}
+        for x in evs[bounds[r]:bounds[r + 1]]:
+            seen.setdefault((int(x["inverted"]), int(x["pos"])), []).append(x)
+        i = np.zeros(1, np.uint64)
+        s = np.full(1, ora.NOSCORE_INIT, np.float32)
+        for lst in seen.values():
+            for x in lst:
+                ora.lib().ora_update_unique(1, int(x["inverted"]), 0, int(x["pos"]), int(x["totalk"]), C.c_float(float(x["score"])), C.c_float(eps),
+                                            int(x["frag"]), i.ctypes.data, s.ctypes.data)
+        nd += int(i[0] != oinfo[r] or s.view(np.uint32)[0] != oscore.view(np.uint32)[r])
+    return nd
+
+
+@pytest.mark.parametrize("seedl,patl,k,kind,pb", [
+    (32, 100, 3, 0, 0), (32, 100, 3, 2, 29), (32, 100, 3, 3, 14), (16, 60, 4, 3, 13), (16, 60, 4, 2, 13), (16, 60, 4, 0, 0),
+    (64, 150, 5, 0, 0), (64, 150, 5, 2, 15), (64, 150, 5, 3, 13), (36, 80, 3, 3, 12), (20, 120, 2, 0, 0)])
+def test_diverged_copies_random(ora, seedl, patl, k, kind, pb):
+    """The same class at random: every read has 2..4 near-copies on either strand that differ from it in different seed
+    segments / behind the seed, and random qualities 0..40 -- the copies are members of different lists' equal ranges
+    and score differently, so the record depends on the order of the update() calls.  All table kinds, 32-bit and wider
+    signatures; lane matcher and (where four locations do not suffice) wave matcher."""
+    g = synth.random_genome(700_000, seed=900 + seedl, n_frag=3, n_runs=6)
+    b = synth.diverged_copy_reads(g, 700, patl, seedl, seed=901 + patl + kind)
+    p = ora.make_params(seedl=seedl, seedkmax=2, totalkmax=k, scores=1)
+    og = ora.Genome(g.sym, g.frag_start)
+    oinfo, oscore, octr, ev = ora.match_unique(og, ora.Index(og, seedl), p, b.bases, b.qual, b.offsets, want_events=True)
+    ost = unpack_info(oinfo)[0]
+    assert (ost == 4).sum() >= 50 and ((ost == 1) | (ost == 2)).sum() >= 20
+    assert _grouped_delivery_differs(ora, ev, oinfo, oscore, float(np.float32(p.filter_mult * patl))) >= 2, "the case must hold reads whose record depends on the order"
+    m = UniqueMatcher(_opts(seedl, 2, k, 1), prefix_bits=pb, table_kind=kind)
+    m.set_text_symbols(0, g.sym, g.frag_start)
+    m.build_index_block()
+    info, score = m.match_unique(b.bases, b.qual, patl=patl)
+    _compare_unique(info, score, oinfo, oscore, 1)
+    c = m.counters()
+    for kk in ("reads", "lookups", "candidates", "seedpass", "hits"):
+        assert c[kk] == octr[kk], (kk, c[kk], octr[kk])
+    assert c["handed_over"] < b.n_reads // 4, c            # most of them are the lane matcher's
+    m.close()

@@ -99,3 +99,27 @@ def test_unify_matches_order_and_dedup(ora):
     # the unique fold on the same reads says NonUnique
     info, score, _ = ora.match_unique(og, ix, p, bases, qual, off)
     assert list(ora.unpack_record(info)[0]) == [NONU, NONU]
+
+
+def test_near_copies_event_order_decides_the_record(ora):
+    """Scores on: three near-copies X, A, C of a read whose scores lie one epsilon-step apart.  In the reference's
+    order (strand, list, ascending position: matchUniqueImplementation.cpp:407-497 calls ::match list by list,
+    match.hpp:383-413 calls update() entry by entry) the record ends NonUnique; the same events grouped by window
+    (every window's events at its first turn) end Straight at C.  Pins the oracle's event order on this input and shows
+    that a matcher which regroups the events is caught by it (tests/test_gpu_parity.py::test_near_copies_*)."""
+    from real_amd import synth
+    g, b, pos_c = synth.near_copy_case()
+    og = ora.Genome(g.sym, g.frag_start)
+    ix = ora.Index(og, 32)
+    p = ora.make_params(seedl=32, seedkmax=2, totalkmax=3, scores=True)
+    info, score, ctr, ev = ora.match_unique(og, ix, p, b.bases, b.qual, b.offsets, want_events=True)
+    assert [(int(e["list"]), int(e["pos"])) for e in ev] == [
+        (0, 10000), (0, 20000), (1, 10000), (1, 30000), (2, 10000), (2, 20000), (2, 30000), (3, 10000), (4, 10000), (4, 20000),
+        (5, 10000), (5, 30000)]
+    st, fr, er, fi, po = ora.unpack_record(info)
+    assert (int(st[0]), int(po[0]), int(er[0])) == (NONU, pos_c, 1)
+    eps = float(np.float32(p.filter_mult * 100))
+    evs = [(int(e["inverted"]), 0, int(e["pos"]), int(e["totalk"]), float(e["score"]), int(e["frag"])) for e in ev]
+    assert fold(ora, 1, evs, eps)[:2] == (NONU, pos_c)                       # the oracle's own fold, replayed
+    grouped = sorted(evs, key=lambda e: e[2])                               # X*6, A*3, C*3: first-reach order of the windows
+    assert fold(ora, 1, grouped, eps)[:2] == (STR, pos_c)
