@@ -54,14 +54,18 @@ def algorithmic_bytes(c, patl, seedl, scores, hit_bytes_out=0):
             c["seedpass"] * (3 * 18 + 8 + 8 * w_rest) + c["hits"] * (18 + 8 * w_score) + hit_bytes_out)
 
 
-def kernel_source_hash():
+def kernel_source_hash(git_rev=None):
     """sha256 over the sources of the match kernel with comments and white space taken out: profiles/traffic.json records
-    the hash it was measured with, and a figure measured on another kernel is not reported."""
+    the hash it was measured with, and a figure measured on another kernel is not reported.  git_rev: of the files as that
+    commit holds them (collect_profiles.py, for passes that ran on a commit the working tree has moved on from)."""
     import re
     h = hashlib.sha256()
     for f in ("match_kernel.hip", "match_common.h", "kernel_common.h", "real_hip_internal.h"):
-        with open(os.path.join(ROOT, "real_amd", "csrc", f), "r", encoding="utf-8") as fh:
-            src = fh.read()
+        if git_rev:
+            src = subprocess.run(["git", "-C", ROOT, "show", "%s:real_amd/csrc/%s" % (git_rev, f)], stdout=subprocess.PIPE, check=True).stdout.decode("utf-8")
+        else:
+            with open(os.path.join(ROOT, "real_amd", "csrc", f), "r", encoding="utf-8") as fh:
+                src = fh.read()
         src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)      # block comments
         src = re.sub(r"//[^\n]*", " ", src)                    # line comments (no string of these files holds "//")
         h.update(" ".join(src.split()).encode())
@@ -170,6 +174,37 @@ def strided_sample(torch, bases, qual, n_reads, patl, k):
     return b, q, off, stride, k
 
 
+def host_cpu_info():
+    """what the box's host side is: CPU model, logical CPUs of the machine, CPUs this process may run on (affinity mask, cgroup
+    quota) -- the CPU baseline states them (north_star: "timed on the same box's host cores (core count stated)")"""
+    model, phys = None, set()
+    try:
+        pid = cid = None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name") and model is None:
+                model = ln.split(":", 1)[1].strip()
+            elif ln.startswith("physical id"):
+                pid = ln.split(":", 1)[1].strip()
+            elif ln.startswith("core id"):
+                cid = ln.split(":", 1)[1].strip()
+            elif not ln.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:                                                        # cgroup v2: "max 100000" or "<quota> <period>"
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    return {"cpu_model": model, "logical_cpus": os.cpu_count(), "physical_cores": len(phys) or None,
+            "usable_cpus": usable, "cgroup_cpu_quota": quota}
+
+
 class CpuSide:
     """The oracle (a port of the reference's OpenMP/popcnt path) on this box's host cores, over the SAME genome and
     the SAME index (the six sorted lists downloaded from the GPU).  Checker and reported baseline only."""
@@ -192,8 +227,11 @@ class CpuSide:
         return self.ora.make_params(seedl=opts.seedl, seedkmax=opts.seedkmax, totalkmax=opts.totalkmax, scores=opts.scores,
                                     filter_level=opts.filter_level, threads=self.threads)
 
-    def baseline_unique(self, torch, opts, bases, qual, patl, n_reads, target_s):
-        """timed on a bounded strided sample of the step's reads, sized by a pilot run for about target_s of CPU work"""
+    def baseline_unique(self, torch, opts, bases, qual, patl, n_reads, target_s, second_threads=8, second_s=8.0):
+        """timed on a bounded strided sample of the step's reads, sized by a pilot run for about target_s of CPU work on
+        self.threads threads (all the CPUs this process may use, unless --cpu-threads says otherwise); a second, shorter leg
+        on `second_threads` threads (the reference's container figures are 8-thread figures) over a prefix of
+        the same sample."""
         ora, p = self.ora, self.params(opts)
         k0 = min(n_reads, 50_000)
         b, q, off, _, _ = strided_sample(torch, bases, qual, n_reads, patl, k0)
@@ -205,6 +243,16 @@ class CpuSide:
                "sample": "%d of the step's %d reads (strided), same %.0f Mbp genome and index (six sorted lists downloaded "
                          "from the GPU), oracle/real_oracle.c with OpenMP, %.1f s of CPU work (+%.0f s index transfer/setup)"
                          % (k1, n_reads, self.og.n / 1e6, dt, self.setup_s)}
+        rep.update(host_cpu_info())
+        legs = [{"threads": self.threads, "reads_per_s": k1 / dt, "reads": k1, "seconds": dt}]
+        if second_threads and second_threads != self.threads and second_s > 0:
+            k2 = int(min(k1, max(10_000, (k1 / dt) * second_s * second_threads / max(self.threads, 1))))
+            p2 = self.ora.make_params(seedl=opts.seedl, seedkmax=opts.seedkmax, totalkmax=opts.totalkmax, scores=opts.scores,
+                                      filter_level=opts.filter_level, threads=second_threads)
+            t = time.time(); i2, s2, _ = ora.match_unique(self.og, self.ix, p2, b[:k2 * patl], q[:k2 * patl], off[:k2 + 1]); dt2 = time.time() - t
+            legs.append({"threads": second_threads, "reads_per_s": k2 / dt2, "reads": k2, "seconds": dt2,
+                         "same_records_as_first_leg": bool(np.array_equal(i2, oinfo[:k2]) and np.array_equal(s2.view(np.uint32), oscore[:k2].view(np.uint32)))})
+        rep["legs"] = legs
         return rep, (stride, k1, oinfo, oscore)
 
 
@@ -225,6 +273,7 @@ def timed_unique(torch, dist, m, rlib, bases, qual, patl, n, steps, warmup, worl
         bufs.append((torch.zeros_like(info), torch.empty_like(score)))
     stepno = [0]
     last = [0]
+    exposed = [0.0]     # seconds this rank stood waiting for a gather inside the timed region (N > 1)
 
     def step():
         slot = stepno[0] % len(bufs)
@@ -232,7 +281,11 @@ def timed_unique(torch, dist, m, rlib, bases, qual, patl, n, steps, warmup, worl
         last[0] = slot
         bi, bs = bufs[slot]
         if rg is not None:
+            tw = time.perf_counter()
             rg.wait(slot)                                       # the gather that last read this buffer
+            if gather_dev != "cpu":
+                torch.cuda.current_stream().synchronize()       # (an RCCL wait only holds the stream: make the host see it)
+            exposed[0] += time.perf_counter() - tw
         bi.zero_(); bs.fill_(NO_SCORE)                          # uniqueinfo(numpat): state NoMatch, score -FLT_MAX
         m.match_unique(bases, qual, patl=patl, info=bi, score=bs, n_reads=n, packed=packed)
         if rg is not None:                                      # the one collective: records to the root
@@ -256,18 +309,38 @@ def timed_unique(torch, dist, m, rlib, bases, qual, patl, n, steps, warmup, worl
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    exposed[0] = 0.0
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    td = time.perf_counter()
     drain()                                                    # every step's records have reached the root
+    if world > 1 and gather_dev != "cpu":
+        torch.cuda.current_stream().synchronize()
+    t_drain = time.perf_counter() - td
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    gather_diag = None
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=gather_dev)
+        # MAX over ranks of the wall time, of the time a rank stood waiting for a gather between steps, and of the final drain
+        tt = torch.tensor([dt, exposed[0], t_drain], dtype=torch.float64, device=gather_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt, w_max, d_max = (float(x) for x in tt.tolist())
+        rec_bytes = 12 * n                                      # u64 record + float score per read
+        gather_diag = {
+            "gather_exposed_ms_per_step": (w_max + d_max) / steps * 1e3,
+            "gather_wait_between_steps_ms_per_step": w_max / steps * 1e3,
+            "gather_final_drain_ms": d_max * 1e3,
+            "gather_bytes_per_rank_per_step": rec_bytes,
+            "gather_GBps_per_link_needed": rec_bytes / (dt / steps) / 1e9,
+            "gather_GBps_into_root_needed": (world - 1) * rec_bytes / (dt / steps) / 1e9,
+            "note": "records of step k travel while step k+1 is matched (two alternating buffers); exposed = MAX over ranks of the time a rank "
+                    "waited for a gather before reusing its buffer, plus the drain of the last step's gather, per timed step; the GB/s are what "
+                    "the step rate asks of one xGMI link (peer -> root) and of the root's links together",
+        }
+    timed_unique.gather_diag = gather_diag
     return dt, m.counters(), m.kernel_time(rlib.K_MATCH_UNIQUE), m.kernel_time(rlib.K_MATCH_REPEAT), bufs[last[0]]
 
 
@@ -337,19 +410,22 @@ def roofline_block(ctr, kernel_ms, launches, patl, seedl, scores, kernel_name, h
             "work_per_read": {k: ctr[k] / max(ctr["reads"], 1) for k in ("lookups", "probes", "candidates", "seedpass", "hits", "verified")}}
 
 
-def recorded_traffic(args, n):
-    """HBM bytes per launch of the match kernel from the rocprofv3 PMC passes (profiles/traffic.json) -- only for the
-    profiled configuration and only if it was measured on the kernel source that is running now."""
+def traffic_key(mode, patl, seedl, totalk, genome_mbp, n, fmt):
+    return "match_%s_%dbp_l%d_k%d_%dMbp_%dreads_%s" % (mode, patl, seedl, totalk, int(genome_mbp), n, fmt)
+
+
+def recorded_traffic(mode, patl, seedl, totalk, scores, genome_mbp, n, fmt, shuffled=False):
+    """HBM bytes per launch of the match kernel from the rocprofv3 PMC passes (profiles/traffic.json) -- only for a
+    profiled configuration (C2, C3, C5) and only if it was measured on the kernel source that is running now."""
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
-    if not os.path.exists(tfile) or (args.patl, args.seedl, args.totalk, args.scores) != (100, 32, 3, 1) or args.shuffle_reads:
-        return None, "not the profiled configuration"
+    if not os.path.exists(tfile) or not scores or shuffled:
+        return None, "not a profiled configuration"
     try:
-        fmt = "packed" if (args.input_format == "packed" and (n * args.patl) % 4 == 0) else "bytes"
-        tj = json.load(open(tfile)).get("match_unique_%dMbp_%dreads_%s" % (int(args.genome_mbp), n, fmt), {})
+        tj = json.load(open(tfile)).get(traffic_key(mode, patl, seedl, totalk, genome_mbp, n, fmt), {})
     except Exception:
         return None, "profiles/traffic.json unreadable"
     if not tj:
-        return None, "not the profiled configuration"
+        return None, "not a profiled configuration"
     if tj.get("kernel_source_sha") != kernel_source_hash():
         return None, "profiles/traffic.json was measured on another kernel source (sha %s, running %s)" % (tj.get("kernel_source_sha"), kernel_source_hash())
     return tj.get("hbm_bytes_per_launch"), "rocprofv3 PMC passes of round %s on this kernel source: 2 x FETCH_SIZE + WRITE_SIZE" % tj.get("round")
@@ -369,7 +445,7 @@ def main():
     ap.add_argument("--prefix-bits", type=int, default=0)
     ap.add_argument("--table-kind", type=int, default=0, help="device bucket tables: 0 auto, 1 starts, 2 directory, 3 bucket rows (real_hip.h)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline's main leg (0 = all the CPUs this process may run on); a second leg runs on 8")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work the baseline sample is sized for (a bounded sample; 40 covers all 50M reads on 16 threads)")
     ap.add_argument("--mode", choices=["unique", "all", "ingest"], default="unique",
                     help="unique = BASELINE configs[1] (default, what the driver runs); all = configs[2] (matchAll)")
@@ -448,10 +524,14 @@ def main():
     n_entries, _ = m.build_index_block()
     t_index = time.time() - t0
     ibs = m.index_build_stats()
-    index_build = {"wall_s": t_index, "kernel_s": ibs["kernel_ms"] / 1e3, "hipMalloc_s": ibs["alloc_ms"] / 1e3, "hipFree_s": ibs["free_ms"] / 1e3,
-                   "allocated_GB": ibs["alloc_bytes"] / 1e9, "hipMalloc_calls": ibs["alloc_calls"]}
-    log("index built: %d entries, prefix_bits %d, %.1f s wall = %.1f s kernels + %.1f s hipMalloc (%.0f GB) + %.1f s hipFree + rest"
-        % (n_entries, m.prefix_bits, t_index, index_build["kernel_s"], index_build["hipMalloc_s"], index_build["allocated_GB"], index_build["hipFree_s"]))
+    index_build = {"wall_s": t_index, "kernel_s": ibs["kernel_ms"] / 1e3, "hipMalloc_s": ibs["alloc_ms"] / 1e3,
+                   "hipMalloc_exposed_s": ibs["alloc_exposed_ms"] / 1e3, "hipFree_s": ibs["free_ms"] / 1e3,
+                   "allocated_GB": ibs["alloc_bytes"] / 1e9, "hipMalloc_calls": ibs["alloc_calls"],
+                   "note": "hipMalloc_s = time inside hipMalloc on any thread; the row arrays come from a helper thread while the lists are "
+                           "sorted, hipMalloc_exposed_s is what the build itself stood waiting for memory (part of wall_s)"}
+    log("index built: %d entries, prefix_bits %d, %.1f s wall = %.1f s kernels + %.1f s waiting for hipMalloc (%.1f s inside it, %.0f GB) + %.1f s hipFree + rest"
+        % (n_entries, m.prefix_bits, t_index, index_build["kernel_s"], index_build["hipMalloc_exposed_s"], index_build["hipMalloc_s"],
+           index_build["allocated_GB"], index_build["hipFree_s"]))
     n = args.reads
     bases, qual, true_pos, true_inv = gen_reads(torch, sym, n, args.patl, 0.02, 4 + rank, dev, shuffle=args.shuffle_reads)
     log("reads generated")
@@ -489,11 +569,15 @@ def main():
                    "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic", "side_measurement": True,
                    "config": {"workload": "matchAll, %dM synthetic %d bp FASTQ reads per GPU vs %.0f Mbp synthetic genome, k=%d, scores %s, %dxMI355X"
                                           % (n // 1_000_000, args.patl, args.genome_mbp, args.totalk, "on" if args.scores else "off", world),
+                              "genome_bp": G, "reads_per_gpu_per_step": n, "read_len": args.patl,
+                              "input_format": "2-bit packed bases" if packed else "one symbol per byte",
                               "hits_per_step_rank0": nh, "hits_gathered_on_root_per_step": nroot, "distributed": dist_info,
                               "parallelism": "reads sharded x%d, index replicated, hit lists gathered to rank 0 (counts first, then payload)" % world},
                    "roofline": roofline_block(ctr, mk, ml, args.patl, args.seedl, bool(args.scores),
                                               "match_kernel<W=%d,scores=%d,all,tables=%s>" % ((args.patl + 31) // 32, args.scores, TABLE_KINDS[m.table_kind]),
-                                              hit_bytes_out=16 * nh * max(ml, 1)),
+                                              hit_bytes_out=16 * nh * max(ml, 1),
+                                              traffic=recorded_traffic("all", args.patl, args.seedl, args.totalk, args.scores, args.genome_mbp, n,
+                                                                       "packed" if packed else "bytes", args.shuffle_reads)[0]),
                    "order_pass_avg_ms": kt["order"][0] / max(kt["order"][1], 1), "cpu_baseline": None}
             print(json.dumps(out), flush=True)
         if world > 1:
@@ -513,17 +597,21 @@ def main():
         value = world * n * K / dt
         st = (info >> 61) & 7
         aligned = int(((st == 1) | (st == 2)).sum().item())
-        traffic, traffic_note = recorded_traffic(args, n)
+        traffic, traffic_note = recorded_traffic("unique", args.patl, args.seedl, args.totalk, args.scores, args.genome_mbp, n,
+                                                 "packed" if packed else "bytes", args.shuffle_reads)
         kname = "match_kernel<W=%d,scores=%d,unique,tables=%s>" % ((args.patl + 31) // 32, args.scores, TABLE_KINDS[m.table_kind])
         roof = roofline_block(ctr, match_ms, match_n, args.patl, args.seedl, bool(args.scores), kname, traffic=traffic)
         roof["traffic_source"] = traffic_note
         roof["repeat_pass_avg_ms"] = rep_ms / max(rep_n, 1)
+        if world > 1 and timed_unique.gather_diag:
+            dist_info.update(timed_unique.gather_diag)
         out = {
             "metric": METRIC,
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "aligned_reads_per_s": value * aligned / n,
+            "value_per_gpu": value / world,
             "config": {"workload": "matchUnique, %dM synthetic %d bp FASTQ reads per GPU vs %.0f Mbp synthetic genome, "
                                    "k=%d (seed k<=2), scores %s, %dxMI355X" % (n // 1_000_000, args.patl, args.genome_mbp,
                                                                                args.totalk, "on" if args.scores else "off", world),
@@ -542,7 +630,9 @@ def main():
         }
         cpu = None
         if want_cpu:
-            cpu = CpuSide(m, sym_host, frag, opts, args.cpu_threads)
+            hc = host_cpu_info()
+            all_threads = max(1, min(hc["usable_cpus"], int(hc["cgroup_cpu_quota"]) if hc["cgroup_cpu_quota"] and hc["cgroup_cpu_quota"] >= 1 else hc["usable_cpus"]))
+            cpu = CpuSide(m, sym_host, frag, opts, args.cpu_threads or all_threads)
             cb, (stride, k1, oinfo, oscore) = cpu.baseline_unique(torch, opts, bases, qual, args.patl, n, args.cpu_seconds)
             # the sample doubles as a full-size parity check: GPU records of the sampled reads == CPU port
             gi = info[::stride][:k1].contiguous().cpu().numpy().view(np.uint64)
@@ -622,7 +712,8 @@ def extras(torch, dist, rlib, args, m, opts, cpu, sym, sym_host, frag, reads, n,
               "order_pass_avg_ms": kt["order"][0] / max(kt["order"][1], 1),
               "roofline": roofline_block(ctr, mk, ml, patl, args.seedl, True,
                                          "match_kernel<W=%d,scores=1,all,tables=%s>" % ((patl + 31) // 32, TABLE_KINDS[m.table_kind]),
-                                         hit_bytes_out=16 * nh * max(ml, 1))}
+                                         hit_bytes_out=16 * nh * max(ml, 1),
+                                         traffic=recorded_traffic("all", patl, args.seedl, 2, 1, args.genome_mbp, n, "packed" if pk is not None else "bytes")[0])}
         if cpu is not None:     # parity on a sample: the oracle's unified hit lists of 200k of the step's reads == the device's
             b, q, off, stride, k1 = strided_sample(torch, bases, qual, n, patl, 200_000)
             p2 = cpu.params(m.opts)
@@ -671,8 +762,10 @@ def extras(torch, dist, rlib, args, m, opts, cpu, sym, sym_host, frag, reads, n,
               "ms_per_step": dt / K * 1e3, "reads_per_s": n * K / dt, "uniquely_aligned_frac": float(al.float().mean().item()),
               "input_format": "2-bit packed bases" if p5 else "one symbol per byte",
               "index_build_s": t_ix5, "index_build_kernel_s": ibs5["kernel_ms"] / 1e3, "index_build_hipMalloc_s": ibs5["alloc_ms"] / 1e3,
+              "index_build_hipMalloc_exposed_s": ibs5["alloc_exposed_ms"] / 1e3,
               "index_build_hipFree_s": ibs5["free_ms"] / 1e3, "bucket_tables": TABLE_KINDS[m5.table_kind], "prefix_bits": m5.prefix_bits,
-              "roofline": roofline_block(ctr, ms, ln, 150, 64, True, "match_kernel<W=5,scores=1,unique,tables=%s>" % TABLE_KINDS[m5.table_kind]),
+              "roofline": roofline_block(ctr, ms, ln, 150, 64, True, "match_kernel<W=5,scores=1,unique,tables=%s>" % TABLE_KINDS[m5.table_kind],
+                                         traffic=recorded_traffic("unique", 150, 64, 5, 1, args.genome_mbp, n, "packed" if p5 else "bytes")[0]),
               "repeat_pass_avg_ms": rms / max(rn, 1)}
         # check on a sample against the oracle's text functions (its 64-bit index does not fit the host beside everything else):
         # every uniquely aligned read of the sample sits where it was cut from, with the mismatch count and the score bits the

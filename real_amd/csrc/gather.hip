@@ -76,22 +76,44 @@ __global__ void rebase_offsets_kernel(const uint64_t *__restrict__ in, uint64_t 
     if (i < n_plus_1) out[i] = in[i] + hits_before;
 }
 
-// counts first: {n_reads, n_hits, capacity for reads, capacity for hits} of every rank, known to every rank afterwards
-// (so that a too small buffer on the root is an error on ALL ranks and nobody is left waiting in a send)
-int exchange_counts(real_hip_ctx *ctx, uint64_t n_local, uint64_t n_hits, uint64_t cap_reads, uint64_t cap_hits, std::vector<uint64_t> &all)
+// counts first: {n_reads, n_hits, capacity for reads, capacity for hits, status} of every rank, known to every rank
+// afterwards.  status = what the rank found wrong on its own side BEFORE the exchange (bad arguments, a scratch buffer it
+// could not reserve: RH_ST_ERR | code) and which receive arrays it was given (RH_ST_HAS_*).  Every decision to give up is
+// taken from the exchanged tuples alone, so it is the same on ALL ranks and is taken before any rank posts a send or a
+// receive: nobody is left waiting in a send to a root that has returned.  (A rank with a local error still takes part in
+// the exchange -- its peers are in it.)
+#define RH_CNT 5
+#define RH_ST_ERR 0x8000ull       /* low 15 bits: -(status code) of the rank's local error */
+#define RH_ST_HAS_A 0x10000ull    /* root: info_all / hits_all given */
+#define RH_ST_HAS_B 0x20000ull    /* root: score_all / offsets_all given */
+int exchange_counts(real_hip_ctx *ctx, uint64_t n_local, uint64_t n_hits, uint64_t cap_reads, uint64_t cap_hits, uint64_t status, std::vector<uint64_t> &all)
 {
     RcclApi *R = rccl();
     const int nr = ctx->comm_size;
-    int rc = rh_reserve(ctx, ctx->comm_counts, (size_t)(nr + 1) * 4 * 8);
-    if (rc) return rc;
+    int rc = rh_reserve(ctx, ctx->comm_counts, (size_t)(nr + 1) * RH_CNT * 8);
+    if (rc) return rc; // (a few hundred bytes: if this fails the device is gone and the peers' collective fails with it)
     uint64_t *d = (uint64_t *)ctx->comm_counts.p;
-    const uint64_t mine[4] = {n_local, n_hits, cap_reads, cap_hits};
-    RH_HIP(ctx, hipMemcpyAsync(d + 4 * (size_t)nr, mine, sizeof mine, hipMemcpyHostToDevice, ctx->stream));
-    RH_NCCL(ctx, R->AllGather(d + 4 * (size_t)nr, d, 4, ncclUint64, (ncclComm_t)ctx->comm, ctx->stream));
-    all.assign((size_t)nr * 4, 0);
-    RH_HIP(ctx, hipMemcpyAsync(all.data(), d, (size_t)nr * 4 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    const uint64_t mine[RH_CNT] = {n_local, n_hits, cap_reads, cap_hits, status};
+    RH_HIP(ctx, hipMemcpyAsync(d + RH_CNT * (size_t)nr, mine, sizeof mine, hipMemcpyHostToDevice, ctx->stream));
+    RH_NCCL(ctx, R->AllGather(d + RH_CNT * (size_t)nr, d, RH_CNT, ncclUint64, (ncclComm_t)ctx->comm, ctx->stream));
+    all.assign((size_t)nr * RH_CNT, 0);
+    RH_HIP(ctx, hipMemcpyAsync(all.data(), d, (size_t)nr * RH_CNT * 8, hipMemcpyDeviceToHost, ctx->stream));
     RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return REAL_HIP_OK;
+}
+// the first rank that reported a local error, or -1
+int first_failed_rank(const std::vector<uint64_t> &all, int nr, int *code)
+{
+    for (int p = 0; p < nr; ++p)
+        if (all[RH_CNT * (size_t)p + 4] & RH_ST_ERR) { *code = -(int)(all[RH_CNT * (size_t)p + 4] & 0x7fffull); return p; }
+    return -1;
+}
+int peer_failed(real_hip_ctx *ctx, int me, int p, int code, const char *mine)
+{
+    if (p == me) return rh_fail(ctx, code, mine, hipSuccess);
+    char msg[160];
+    snprintf(msg, sizeof msg, "rank %d gave up before the gather (%s); no data was exchanged", p, real_hip_strerror(code));
+    return rh_fail(ctx, code, msg, hipSuccess);
 }
 
 // payload: rank r's `bytes[r]` bytes from `send` to the root's `recv + offset[r]`; one group, every peer on its own link
@@ -159,17 +181,28 @@ extern "C" int real_hip_gather_records(real_hip_ctx *ctx, int root, const uint64
     if (!ctx) return REAL_HIP_E_INVALID;
     RH_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->comm) return rh_fail(ctx, REAL_HIP_E_STATE, "real_hip_comm_init first", hipSuccess);
-    if (root < 0 || root >= ctx->comm_size || (n_local && !info)) return rh_fail(ctx, REAL_HIP_E_INVALID, "gather arguments", hipSuccess);
+    if (root < 0 || root >= ctx->comm_size) return rh_fail(ctx, REAL_HIP_E_INVALID, "gather arguments: root (must be the same valid rank on every rank)", hipSuccess);
     const int nr = ctx->comm_size, me = ctx->comm_rank;
+    const char *why = "gather arguments";
+    uint64_t status = (n_local && !info) ? (RH_ST_ERR | (uint64_t)(-REAL_HIP_E_INVALID)) : 0;
+    if (me == root) status |= (info_all ? RH_ST_HAS_A : 0) | (score_all ? RH_ST_HAS_B : 0);
     std::vector<uint64_t> all;
-    int rc = exchange_counts(ctx, n_local, 0, me == root ? cap_all : 0, 0, all);
+    int rc = exchange_counts(ctx, n_local, score ? 1 : 0, me == root ? cap_all : 0, 0, status, all);
     if (rc) return rc;
+    int code = 0;
+    const int bad = first_failed_rank(all, nr, &code);
+    if (bad >= 0) return peer_failed(ctx, me, bad, code, why);
     uint64_t total = 0;
     std::vector<uint64_t> bi((size_t)nr), oi((size_t)nr), bs((size_t)nr), os((size_t)nr);
-    for (int p = 0; p < nr; ++p) { oi[(size_t)p] = total * 8; os[(size_t)p] = total * 4; bi[(size_t)p] = all[4 * (size_t)p] * 8; bs[(size_t)p] = all[4 * (size_t)p] * 4; total += all[4 * (size_t)p]; }
+    for (int p = 0; p < nr; ++p) { oi[(size_t)p] = total * 8; os[(size_t)p] = total * 4; bi[(size_t)p] = all[RH_CNT * (size_t)p] * 8; bs[(size_t)p] = all[RH_CNT * (size_t)p] * 4; total += all[RH_CNT * (size_t)p]; }
     if (n_all) *n_all = total;
-    if (total > all[4 * (size_t)root + 2]) return rh_fail(ctx, REAL_HIP_E_OVERFLOW, "the root's record arrays are too small (every rank reports this)", hipSuccess);
-    if (me == root && total && (!info_all || (score && !score_all))) return rh_fail(ctx, REAL_HIP_E_INVALID, "null receive arrays on the root", hipSuccess);
+    if (total > all[RH_CNT * (size_t)root + 2]) return rh_fail(ctx, REAL_HIP_E_OVERFLOW, "the root's record arrays are too small (every rank reports this)", hipSuccess);
+    // (every rank sees what the root was given and whether the root gathers scores: the same verdict everywhere)
+    const uint64_t rs = all[RH_CNT * (size_t)root + 4];
+    const bool root_scores = all[RH_CNT * (size_t)root + 1] != 0;
+    if (total && (!(rs & RH_ST_HAS_A) || (root_scores && !(rs & RH_ST_HAS_B))))
+        return rh_fail(ctx, REAL_HIP_E_INVALID, "null receive arrays on the root (every rank reports this)", hipSuccess);
+    if ((score != nullptr) != root_scores) return rh_fail(ctx, REAL_HIP_E_INVALID, "score arrays on some ranks only", hipSuccess);
     if ((rc = gather_bytes(ctx, root, info, bi, info_all, oi))) return rc;
     if (score && (rc = gather_bytes(ctx, root, score, bs, score_all, os))) return rc;
     RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -183,15 +216,29 @@ extern "C" int real_hip_gather_hits(real_hip_ctx *ctx, int root, const real_hip_
     if (!ctx) return REAL_HIP_E_INVALID;
     RH_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->comm) return rh_fail(ctx, REAL_HIP_E_STATE, "real_hip_comm_init first", hipSuccess);
-    if (root < 0 || root >= ctx->comm_size || !hit_offsets || (n_hits_local && !hits)) return rh_fail(ctx, REAL_HIP_E_INVALID, "gather arguments", hipSuccess);
+    if (root < 0 || root >= ctx->comm_size) return rh_fail(ctx, REAL_HIP_E_INVALID, "gather arguments: root (must be the same valid rank on every rank)", hipSuccess);
     const int nr = ctx->comm_size, me = ctx->comm_rank;
+    const char *why = "gather arguments";
+    uint64_t status = (!hit_offsets || (n_hits_local && !hits)) ? (RH_ST_ERR | (uint64_t)(-REAL_HIP_E_INVALID)) : 0;
+    uint64_t *scratch = nullptr;
+    if (me == root) {
+        status |= (hits_all ? RH_ST_HAS_A : 0) | (offsets_all ? RH_ST_HAS_B : 0);
+        // the shards' offset arrays side by side: reserved for what the caller's offsets_all can hold, BEFORE the exchange,
+        // so that a failure here is every rank's knowledge before anyone sends
+        const int rr = rh_reserve(ctx, ctx->comm_scratch, (size_t)(cap_reads + (uint64_t)nr + 1) * 8);
+        if (rr && !(status & RH_ST_ERR)) { status |= RH_ST_ERR | (uint64_t)(-rr); why = "scratch for the gathered offsets"; }
+        scratch = (uint64_t *)ctx->comm_scratch.p;
+    }
     std::vector<uint64_t> all;
-    int rc = exchange_counts(ctx, n_local, n_hits_local, me == root ? cap_reads : 0, me == root ? cap_hits : 0, all);
+    int rc = exchange_counts(ctx, n_local, n_hits_local, me == root ? cap_reads : 0, me == root ? cap_hits : 0, status, all);
     if (rc) return rc;
+    int code = 0;
+    const int bad = first_failed_rank(all, nr, &code);
+    if (bad >= 0) return peer_failed(ctx, me, bad, code, why);
     uint64_t reads = 0, nh = 0;
     std::vector<uint64_t> bh((size_t)nr), oh((size_t)nr), bo((size_t)nr), oo((size_t)nr), first((size_t)nr), before((size_t)nr);
     for (int p = 0; p < nr; ++p) {
-        const uint64_t n = all[4 * (size_t)p], h = all[4 * (size_t)p + 1];
+        const uint64_t n = all[RH_CNT * (size_t)p], h = all[RH_CNT * (size_t)p + 1];
         first[(size_t)p] = reads; before[(size_t)p] = nh;
         oh[(size_t)p] = nh * sizeof(real_hip_hit); bh[(size_t)p] = h * sizeof(real_hip_hit);
         oo[(size_t)p] = (reads + (uint64_t)p) * 8; bo[(size_t)p] = (n + 1) * 8; // the shards' offset arrays side by side in a scratch
@@ -199,20 +246,17 @@ extern "C" int real_hip_gather_hits(real_hip_ctx *ctx, int root, const real_hip_
     }
     if (n_reads_all) *n_reads_all = reads;
     if (n_hits_all) *n_hits_all = nh;
-    if (reads > all[4 * (size_t)root + 2] || nh > all[4 * (size_t)root + 3])
+    if (reads > all[RH_CNT * (size_t)root + 2] || nh > all[RH_CNT * (size_t)root + 3])
         return rh_fail(ctx, REAL_HIP_E_OVERFLOW, "the root's hit / offset arrays are too small (every rank reports this)", hipSuccess);
     if (reads > 0xffffffffull) return rh_fail(ctx, REAL_HIP_E_INVALID, "more than 2^32 reads in the gathered batch (real_hip_hit.read is 32 bit)", hipSuccess);
-    if (me == root && ((nh && !hits_all) || !offsets_all)) return rh_fail(ctx, REAL_HIP_E_INVALID, "null receive arrays on the root", hipSuccess);
-    uint64_t *scratch = nullptr;
-    if (me == root) {
-        if ((rc = rh_reserve(ctx, ctx->comm_scratch, (size_t)(reads + (uint64_t)nr) * 8))) return rc;
-        scratch = (uint64_t *)ctx->comm_scratch.p;
-    }
+    const uint64_t rs = all[RH_CNT * (size_t)root + 4];
+    if ((nh && !(rs & RH_ST_HAS_A)) || !(rs & RH_ST_HAS_B))
+        return rh_fail(ctx, REAL_HIP_E_INVALID, "null receive arrays on the root (every rank reports this)", hipSuccess);
     if ((rc = gather_bytes(ctx, root, hits, bh, hits_all, oh))) return rc;
     if ((rc = gather_bytes(ctx, root, hit_offsets, bo, scratch, oo))) return rc;
     if (me == root) {
         for (int p = 0; p < nr; ++p) {
-            const uint64_t n = all[4 * (size_t)p], h = all[4 * (size_t)p + 1];
+            const uint64_t n = all[RH_CNT * (size_t)p], h = all[RH_CNT * (size_t)p + 1];
             if (h && first[(size_t)p])
                 hipLaunchKernelGGL(rebase_hits_kernel, dim3((unsigned)((h + 255) / 256)), dim3(256), 0, ctx->stream, hits_all + before[(size_t)p], h, (uint32_t)first[(size_t)p]);
             // (n + 1 entries: the last one of rank p is overwritten by the first one of rank p + 1 -- the same value)

@@ -1102,7 +1102,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
     const uint64_t rc = r < n ? r : n; // lanes behind the batch: an empty range at its end
     const uint64_t o0 = a.b.off ? a.b.off[rc] : rc * (uint64_t)a.b.upatl;
     const uint64_t o1 = r < n ? (a.b.off ? a.b.off[r + 1] : o0 + a.b.upatl) : o0;
-    const uint32_t patl = (uint32_t)(o1 - o0);
+    // (the span in 64 bits first: offsets that run backwards or jump by 2^32 and more must not alias to a short read)
+    const bool span_bad = o1 < o0 || o1 - o0 > (uint64_t)REAL_HIP_MAX_PATL_LONG;
+    const uint32_t patl = span_bad ? 0u : (uint32_t)(o1 - o0);
     const uint32_t bsh = a.b.packed ? 2u : 0u; // packed bases: four per byte
     const uint32_t GL = a.b.gl; // reads the wave stages at a time: GL * max_patl fits its LDS region
     const uint32_t stg_cap = stg_bytes(W, TK) - STG_PAD - 32u; // bytes of a group the region holds (skew, pad, over-read)
@@ -1120,9 +1122,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
         if (fits) l0 = stage_wave(stg, a.b.bases + (gb >> bsh), a.b.packed ? ((ge + 3) >> 2) - (gb >> 2) : ge - gb, lane);
         wave_lds_sync();
         const bool in_group = lane >= g && lane < g + GL && r < n;
-        if (in_group && (o1 < o0 || patl > REAL_HIP_MAX_PATL_LONG)) toolong = true;
+        if (in_group && span_bad) toolong = true;
         else if (in_group && (!fits || patl > 32u * W)) give = patl >= a.l;
-        if (in_group && fits && o1 >= o0 && patl >= a.l && patl <= 32u * W) { // matchUniqueImplementation.cpp:376-394
+        if (in_group && fits && !span_bad && patl >= a.l && patl <= 32u * W) { // matchUniqueImplementation.cpp:376-394
             if (a.b.packed) {
                 pack_read_packed<W>(LdsRow{stg, l0 + (uint32_t)((o0 >> 2) - (gb >> 2))}, patl, (uint32_t)o0 & 3u, s.O);
                 elig = !(a.b.nflags && ((a.b.nflags[r >> 3] >> (r & 7)) & 1)); // a read with a symbol > 3 is flagged, not packed

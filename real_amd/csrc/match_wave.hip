@@ -230,7 +230,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
     for (uint64_t it = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); it < n_items; it += n_waves) { // (wave-uniform trip count)
         const uint64_t r = a.ovf_list[it];
         const uint64_t o0 = a.b.off ? a.b.off[r] : r * (uint64_t)a.b.upatl;
-        const uint32_t patl = a.b.off ? (uint32_t)(a.b.off[r + 1] - o0) : a.b.upatl;
+        const uint64_t span = a.b.off ? a.b.off[r + 1] - o0 : (uint64_t)a.b.upatl; // (64 bits: a span of 2^32 and more must not alias to a short read)
+        const uint32_t patl = span > (uint64_t)REAL_HIP_MAX_PATL_LONG ? 0u : (uint32_t)span; // (0: not eligible below; the lane matcher has raised the error flag)
         // The read sits in the wave's LDS as words of 32 bases, straight and reverse-complemented, whatever its length; every
         // lane walks the words of its own candidate in run-time loops (an LDS word is the same address in all lanes: a
         // broadcast).  Few registers per lane that way: many waves per CU, and this kernel lives on waves in flight.

@@ -59,7 +59,7 @@ void GenomeText::load(const std::string &fasta)
     std::vector<Piece> pc((size_t)nt);
     for (int t = 0; t < nt; ++t) { // cuts at line starts
         size_t lo = n * (size_t)t / (size_t)nt;
-        if (t && lo < n) {
+        if (t && lo > 0 && lo < n) { // (lo == 0: fewer bytes than threads -- offset 0 is a line start, and there is no byte in front of it)
             const void *nl = memchr(data + lo - 1, '\n', n - (lo - 1)); // (the line that holds byte lo-1 ends here)
             lo = nl ? (size_t)((const char *)nl - data) + 1 : n;
         }

@@ -194,3 +194,71 @@ def test_real_cli_long_reads(ora, tmp_path):
     want = expected_unique(ora, g, b, info, score, 1)
     got = open(out).read().split("\n")[:-1]
     assert got == want and sum(1 for l in got if l.split("\t")[5] in ("300", "700")) > 60
+
+
+@pytest.mark.parametrize("extra", [[], ["-block", "25000"], ["-u", "0"]])
+def test_real_cli_genome_directory_of_two_files(ora, tmp_path, extra):
+    """-t <directory>: every .fa file below it is a genome file with its own file id, in readdir order (getFileList.cpp:145-174;
+    matchUniqueImplementation.cpp:1099-1118).  Reads of either file and of a stretch both hold at the same position and
+    fragment number: the latter are NonUnique through the file id alone (:131, :219) and must not be printed; the fragment
+    name of a printed line is that of ITS file.  Expected lines = the oracle run file by file over the same records, in the
+    order `real` says it processed the files."""
+    import importlib
+    tgp = importlib.import_module("test_gpu_parity")
+    g0, g1, b = tgp._two_file_genome()
+    d = tmp_path / "genome"
+    (d / "sub").mkdir(parents=True)
+    synth.genome_to_fasta(g0, str(d / "b_first.fa"))
+    synth.genome_to_fasta(g1, str(d / "sub" / "a_second.fa"))
+    open(str(d / "notes.txt"), "w").write(">not a genome\nACGT\n")          # (no .fa suffix: ignored)
+    rd = str(tmp_path / "reads.fq")
+    synth.reads_to_fastq(b, rd)
+    out = str(tmp_path / "out.tsv")
+    unique = "-u" not in extra
+    r = subprocess.run([REAL, "-t", str(d), "-p", rd, "-o", out, "-e", "3" if unique else "2", "-s", "2", "-l", "32", "-q", "1"] + extra,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    order = [ln.split("Processing file ")[1].split(" (last")[0].strip() for ln in r.stderr.decode().splitlines() if ln.startswith("Processing file ")]
+    assert sorted(os.path.basename(f) for f in order) == ["a_second.fa", "b_first.fa"]
+    files = [g0 if os.path.basename(f) == "b_first.fa" else g1 for f in order]
+    got = open(out).read().split("\n")[:-1]
+    if unique:
+        n_list = 25000 if extra else 0
+        info = np.zeros(b.n_reads, np.uint64)
+        score = np.full(b.n_reads, ora.NOSCORE_INIT, np.float32)
+        for fid, g in enumerate(files):
+            og = ora.Genome(g.sym, g.frag_start)
+            p = ora.make_params(seedl=32, seedkmax=2, totalkmax=3, scores=1, fileid=fid)
+            first = 0
+            while True:
+                ix = ora.Index(og, 32, first, n_list if n_list else 1 << 62)
+                info, score, _ = ora.match_unique(og, ix, p, b.bases, b.qual, b.offsets, info=info, score=score)
+                first += ix.n
+                if not ix.have_next:
+                    break
+        st, fr, er, fi, po = ora.unpack_record(info)
+        want = []
+        for i in range(b.n_reads):
+            if st[i] not in (1, 2):
+                continue
+            g = files[fi[i]]
+            lo, hi = int(b.offsets[i]), int(b.offsets[i + 1])
+            want.append("\t".join([b.ids[i], seq(b.bases[lo:hi], st[i] == 2), fmt_float(score[i]), "1", "a", str(hi - lo), "-" if st[i] == 2 else "+",
+                                    g.frag_names[fr[i]], str(po[i] - int(g.frag_start[fr[i]]) + 1), "", str(er[i])]))
+        assert got == want
+        assert sum(1 for l in got if " zero_" in l) > 500 and sum(1 for l in got if " one_" in l) > 400
+        assert (st[-200:] == 4).sum() >= 150          # the shared stretch: NonUnique through the file id, not printed (got == want)
+    else:
+        # matchAll: file by file, block by block, the hits of every read in unifyMatches order (matchAllImplementation.cpp:451-535)
+        want = []
+        for fid, g in enumerate(files):
+            og = ora.Genome(g.sym, g.frag_start)
+            p = ora.make_params(seedl=32, seedkmax=2, totalkmax=2, scores=1, fileid=fid)
+            hits, hoff, _ = ora.match_all(og, ora.Index(og, 32), p, b.bases, b.qual, b.offsets)
+            for h in hits:
+                i = int(h["read"])
+                lo, hi = int(b.offsets[i]), int(b.offsets[i + 1])
+                want.append("\t".join([b.ids[i], seq(b.bases[lo:hi], bool(h["inverted"])), fmt_float(h["score"]), "1", "a", str(hi - lo),
+                                        "-" if h["inverted"] else "+", g.frag_names[int(h["frag"])],
+                                        str(int(h["pos"]) - int(g.frag_start[int(h["frag"])]) + 1), "", str(int(h["k"]))]))
+        assert got == want

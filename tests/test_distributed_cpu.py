@@ -130,5 +130,12 @@ def test_bench_two_rank_rehearsal_through_the_launcher():
     j = _bench_json(small)
     assert j["n_gpus"] == 2 and j["config"]["distributed"]["world_size"] == 2 and j["config"]["distributed"]["backend"] == "gloo"
     assert j["value"] > 0 and 0.5 < j["config"]["uniquely_aligned_frac_rank0"] < 1
+    # the N > 1 line diagnoses itself: what the gather cost outside the shadow of the next step, and what the step rate asks of a link
+    d = j["config"]["distributed"]
+    for key in ("gather_exposed_ms_per_step", "gather_wait_between_steps_ms_per_step", "gather_final_drain_ms", "gather_bytes_per_rank_per_step",
+                "gather_GBps_per_link_needed", "gather_GBps_into_root_needed"):
+        assert key in d and d[key] >= 0, key
+    assert d["gather_bytes_per_rank_per_step"] == 12 * 200000 and abs(j["value_per_gpu"] * 2 - j["value"]) < 1e-6 * j["value"]
+    assert d["gather_exposed_ms_per_step"] < j["ms_per_step"]
     j = _bench_json(small + ["--mode", "all", "--totalk", "2"])
     assert j["n_gpus"] == 2 and j["config"]["hits_gathered_on_root_per_step"] > j["config"]["hits_per_step_rank0"] > 0

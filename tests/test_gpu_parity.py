@@ -296,6 +296,14 @@ def test_errors_are_loud():
     with pytest.raises(RealHipError):           # longer than REAL_HIP_MAX_PATL_LONG: an error, not a silent skip
         m.match_unique(np.zeros(17000, np.uint8), np.zeros(17000, np.uint8), patl=17000)
     info, score = m.match_unique(np.zeros(300, np.uint8), np.zeros(300, np.uint8), patl=300)     # (longer than the registers hold: a wave's job)
+    # device-resident offsets with a declared max_patl are never scanned by the host: a span of 2^32 + 100 bases must not
+    # alias to a 100-base read inside the kernel -- the kernel raises its flag, the call fails
+    import torch
+    off = torch.tensor([0, 100, (1 << 32) + 200], dtype=torch.int64, device="cuda")
+    zb, zq = torch.zeros(4096, dtype=torch.uint8, device="cuda"), torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    with pytest.raises(RealHipError):
+        m.match_unique(zb, zq, off, max_patl=100, info=torch.zeros(2, dtype=torch.int64, device="cuda"),
+                       score=torch.zeros(2, dtype=torch.float32, device="cuda"))
     assert info.shape[0] == 1
     # empty batch and all-skipped batch are fine
     info, score = m.match_unique(np.zeros(0, np.uint8), np.zeros(0, np.uint8), patl=100, n_reads=0)
@@ -607,4 +615,46 @@ def test_diverged_copies_random(ora, seedl, patl, k, kind, pb):
     for kk in ("reads", "lookups", "candidates", "seedpass", "hits"):
         assert c[kk] == octr[kk], (kk, c[kk], octr[kk])
     assert c["handed_over"] < b.n_reads // 4, c            # most of them are the lane matcher's
+    m.close()
+
+
+def _two_file_genome():
+    """two genome files (file ids 0 and 1, UniqueMatchInfo.hpp:31) that share one 600-base stretch at the SAME position of the
+    SAME fragment number: a read from it has two best hits that differ in the file id alone"""
+    g0 = synth.random_genome(60_000, seed=501, n_runs=3, repeats=6)
+    g1 = synth.random_genome(50_000, seed=502, n_runs=2, repeats=4)
+    g0 = synth.Genome(sym=g0.sym, frag_start=np.array([0, 30_000, 60_000], dtype=np.uint64), frag_names=[" zero_0", " zero_1"])
+    g1 = synth.Genome(sym=g1.sym, frag_start=np.array([0, 20_000, 35_000, 50_000], dtype=np.uint64), frag_names=[" one_0", " one_1", " one_2"])
+    g1.sym[1000:1600] = g0.sym[1000:1600]
+    g0.sym[1000:1600] = np.where(g0.sym[1000:1600] > 3, 0, g0.sym[1000:1600])        # (no N inside the shared stretch)
+    g1.sym[1000:1600] = g0.sym[1000:1600]
+    b0 = synth.sample_reads(g0, 900, 100, 0.02, seed=503)
+    b1 = synth.sample_reads(g1, 700, 100, 0.02, seed=504)
+    sh = synth.sample_reads(synth.Genome(sym=g0.sym[1000:1600].copy(), frag_start=np.array([0, 600], dtype=np.uint64)), 200, 100, 0.01, seed=505)
+    return g0, g1, synth.concat_batches([b0, b1, sh])
+
+
+@pytest.mark.parametrize("scores,kind,pb", [(1, 0, 0), (0, 0, 0), (1, 3, 14), (1, 2, 29)])
+def test_two_genome_files_fold_through_the_file_id(ora, scores, kind, pb):
+    """matchUniqueImplementation.cpp:1099-1118 walks the genome files one after the other over the same uniqueinfo[]; the
+    fold compares the file id (:131, :219).  Reads of file 0, of file 1, and of a stretch both files hold at the same
+    position and fragment (NonUnique through the file id alone); file 1 is matched with fileid 1 in the records."""
+    g0, g1, b = _two_file_genome()
+    info, score = new_unique_info(b.n_reads, scores)
+    oinfo, oscore = new_unique_info(b.n_reads, scores)
+    if oscore is None:
+        oscore = np.full(b.n_reads, ora.NOSCORE_INIT, dtype=np.float32)
+    m = UniqueMatcher(_opts(32, 2, 3, scores), prefix_bits=pb, table_kind=kind)
+    for fid, g in enumerate((g0, g1)):
+        p = ora.make_params(seedl=32, seedkmax=2, totalkmax=3, scores=scores, fileid=fid)
+        og = ora.Genome(g.sym, g.frag_start)
+        oinfo, oscore, _ = ora.match_unique(og, ora.Index(og, 32), p, b.bases, b.qual, b.offsets, info=oinfo, score=oscore)
+        m.set_text_symbols(fid, g.sym, g.frag_start)
+        m.build_index_block()
+        m.match_unique(b.bases, b.qual, b.offsets, info=info, score=score)
+    _compare_unique(info, score, oinfo, oscore, scores)
+    st, fr, er, fi, po = unpack_info(info)
+    uniq = (st == 1) | (st == 2)
+    assert (uniq & (fi == 0)).sum() > 500 and (uniq & (fi == 1)).sum() > 400, "both files have uniquely aligned reads"
+    assert (st[-200:] == 4).sum() >= 150, "reads of the shared stretch are NonUnique through the file id"
     m.close()

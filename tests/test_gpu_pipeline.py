@@ -200,6 +200,15 @@ def test_c_abi_rccl_gather_single_rank():
     with pytest.raises(rlib.RealHipError) as e:                                 # a receive array that is too small: loud, on every rank
         m.gather_records(0, di, ds, ai[:10], as_[:10])
     assert e.value.status == rlib.REAL_HIP_E_OVERFLOW
+    # null receive arrays on the root / a null send array: decided from the exchanged tuples (the same verdict on every rank,
+    # before anyone sends -- ADVICE r2: a root that returned alone left its peers in ncclSend)
+    import ctypes as C
+    n_all = C.c_uint64(0)
+    rc = m._L.real_hip_gather_records(m._h, 0, di.data_ptr(), ds.data_ptr(), n, None, None, n, C.byref(n_all))
+    assert rc == rlib.REAL_HIP_E_INVALID and b"every rank" in m._L.real_hip_last_error(m._h)
+    rc = m._L.real_hip_gather_records(m._h, 0, None, ds.data_ptr(), n, ai.data_ptr(), as_.data_ptr(), n + 5, C.byref(n_all))
+    assert rc == rlib.REAL_HIP_E_INVALID
+    assert m.gather_records(0, di, ds, ai, as_) == n                             # (and the communicator is still usable)
     # matchAll hit lists
     m.set_match_params(totalkmax=2)
     import ctypes as C
@@ -216,4 +225,8 @@ def test_c_abi_rccl_gather_single_rank():
     ao = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
     assert m.gather_hits(0, hits, hoff, nh, ah, ao) == (n, nh)
     assert torch.equal(ah[:nh], hits[:nh]) and torch.equal(ao, hoff)
+    nr_, nh_ = C.c_uint64(0), C.c_uint64(0)
+    rc = m._L.real_hip_gather_hits(m._h, 0, hits.data_ptr(), hoff.data_ptr(), n, nh, ah.data_ptr(), nh + 7, None, n, C.byref(nr_), C.byref(nh_))
+    assert rc == rlib.REAL_HIP_E_INVALID and b"every rank" in m._L.real_hip_last_error(m._h)
+    assert m.gather_hits(0, hits, hoff, nh, ah, ao) == (n, nh)
     m.close()

@@ -36,6 +36,20 @@ def test_genome_loader(selftest, tmp_path):
     assert np.array_equal(np.fromfile(tmp_path / "wild.u64", dtype=np.uint64), wild)
 
 
+@pytest.mark.parametrize("text,sym", [(">a\nAC\n", [0, 1]), (">\nG", [2]), (">x\n", []), ("", [])])
+def test_genome_loader_file_shorter_than_the_thread_count(selftest, tmp_path, text, sym):
+    """the parallel sweeps cut the file into one piece per thread at line starts; with fewer bytes than threads several
+    cuts fall on offset 0, where there is no byte in front to look at (data[-1])"""
+    fa = tmp_path / "tiny.fa"
+    open(fa, "w").write(text)
+    env = dict(os.environ, OMP_NUM_THREADS="64")
+    r = subprocess.run([selftest, "genome", str(fa), str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    if not sym and r.returncode != 0:
+        return                                        # an empty genome may be refused, loudly; it must not crash
+    assert r.returncode == 0, r.stderr.decode()
+    assert np.fromfile(tmp_path / "sym.u8", dtype=np.uint8).tolist() == sym
+
+
 def test_fastq_and_fasta_readers(selftest, tmp_path):
     g = synth.random_genome(20000, seed=4)
     b = synth.concat_batches([synth.sample_reads(g, 20, 36, 0.05, seed=5, n_read_prob=0.02),
