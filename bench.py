@@ -524,14 +524,10 @@ def main():
     n_entries, _ = m.build_index_block()
     t_index = time.time() - t0
     ibs = m.index_build_stats()
-    index_build = {"wall_s": t_index, "kernel_s": ibs["kernel_ms"] / 1e3, "hipMalloc_s": ibs["alloc_ms"] / 1e3,
-                   "hipMalloc_exposed_s": ibs["alloc_exposed_ms"] / 1e3, "hipFree_s": ibs["free_ms"] / 1e3,
-                   "allocated_GB": ibs["alloc_bytes"] / 1e9, "hipMalloc_calls": ibs["alloc_calls"],
-                   "note": "hipMalloc_s = time inside hipMalloc on any thread; the row arrays come from a helper thread while the lists are "
-                           "sorted, hipMalloc_exposed_s is what the build itself stood waiting for memory (part of wall_s)"}
-    log("index built: %d entries, prefix_bits %d, %.1f s wall = %.1f s kernels + %.1f s waiting for hipMalloc (%.1f s inside it, %.0f GB) + %.1f s hipFree + rest"
-        % (n_entries, m.prefix_bits, t_index, index_build["kernel_s"], index_build["hipMalloc_exposed_s"], index_build["hipMalloc_s"],
-           index_build["allocated_GB"], index_build["hipFree_s"]))
+    index_build = {"wall_s": t_index, "kernel_s": ibs["kernel_ms"] / 1e3, "hipMalloc_s": ibs["alloc_ms"] / 1e3, "hipFree_s": ibs["free_ms"] / 1e3,
+                   "allocated_GB": ibs["alloc_bytes"] / 1e9, "hipMalloc_calls": ibs["alloc_calls"]}
+    log("index built: %d entries, prefix_bits %d, %.1f s wall = %.1f s kernels + %.1f s hipMalloc (%.0f GB) + %.1f s hipFree + rest"
+        % (n_entries, m.prefix_bits, t_index, index_build["kernel_s"], index_build["hipMalloc_s"], index_build["allocated_GB"], index_build["hipFree_s"]))
     n = args.reads
     bases, qual, true_pos, true_inv = gen_reads(torch, sym, n, args.patl, 0.02, 4 + rank, dev, shuffle=args.shuffle_reads)
     log("reads generated")
@@ -762,7 +758,6 @@ def extras(torch, dist, rlib, args, m, opts, cpu, sym, sym_host, frag, reads, n,
               "ms_per_step": dt / K * 1e3, "reads_per_s": n * K / dt, "uniquely_aligned_frac": float(al.float().mean().item()),
               "input_format": "2-bit packed bases" if p5 else "one symbol per byte",
               "index_build_s": t_ix5, "index_build_kernel_s": ibs5["kernel_ms"] / 1e3, "index_build_hipMalloc_s": ibs5["alloc_ms"] / 1e3,
-              "index_build_hipMalloc_exposed_s": ibs5["alloc_exposed_ms"] / 1e3,
               "index_build_hipFree_s": ibs5["free_ms"] / 1e3, "bucket_tables": TABLE_KINDS[m5.table_kind], "prefix_bits": m5.prefix_bits,
               "roofline": roofline_block(ctr, ms, ln, 150, 64, True, "match_kernel<W=5,scores=1,unique,tables=%s>" % TABLE_KINDS[m5.table_kind],
                                          traffic=recorded_traffic("unique", 150, 64, 5, 1, args.genome_mbp, n, "packed" if p5 else "bytes")[0]),

@@ -135,15 +135,11 @@ int real_hip_build_index_block(real_hip_ctx *ctx, uint64_t first_window, uint64_
 /* where the wall time of the index builds of this ctx went, accumulated since the last reset: the kernels of the
  * build (HIP events), hipMalloc and hipFree (host clock; the driver maps and clears every page), the rest is
  * synchronisation and host code.  The counterpart of the reference's "Sorting fragments..." clock
- * (ListSetBlockReader.hpp:42-48).  alloc_ms sums the time spent inside hipMalloc on any thread; the row arrays of the
- * bucket-row layout are allocated by a helper thread while the lists are sorted, so alloc_exposed_ms -- what the
- * building thread itself stood waiting for memory -- is the share that is part of wall_ms.  (A caller built against
- * the struct without alloc_exposed_ms passes its smaller struct_size and gets the fields it knows.)             */
+ * (ListSetBlockReader.hpp:42-48).                                                                             */
 typedef struct real_hip_build_stats {
     uint32_t struct_size, reserved;
     double   wall_ms, kernel_ms, alloc_ms, free_ms;
     uint64_t alloc_bytes, alloc_calls, free_calls;
-    double   alloc_exposed_ms;
 } real_hip_build_stats;
 int real_hip_index_build_stats(real_hip_ctx *ctx, real_hip_build_stats *out, int reset);
 /* introspection (tests, CPU baseline): device layout of list k               */

@@ -14,11 +14,7 @@
 //     matchAllImplementation.cpp:122-161).
 #include "real_hip_internal.h"
 
-#include <atomic>
-#include <cstdlib>
 #include <cstring>
-#include <thread>
-#include <vector>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
@@ -409,45 +405,7 @@ int rh_rows_unpack(real_hip_ctx *ctx, int list, uint2 *d_entries, uint32_t *d_st
 //   tables         bucket starts; rows: overflow counts and their scan
 // Persistent outputs (rows / overflow entries, or entries / bucket tables) are allocations of their own.
 // ---------------------------------------------------------------------------
-// The row arrays of the six lists (2^pb x 128 bytes each: 34 GB at 3 Gbp) are persistent outputs whose size is known before
-// anything is sorted, and hipMalloc of 206 GB costs 0.5 .. 5 s (the driver maps and clears every page) against 1.4 s of
-// kernels for the whole build.  They are allocated by a helper thread, list by list in the order the build needs them,
-// while the stream sorts: the build only waits for what has not arrived when a list's rows are to be filled
-// (real_hip_build_stats.alloc_exposed_ms).  REAL_HIP_PREALLOC_THREADS = 0 turns it off, n > 1 spreads the lists over n threads.
-struct RowPrealloc {
-    std::vector<std::thread> th;
-    void *p[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipError_t err[6];
-    double ms[6] = {0, 0, 0, 0, 0, 0};
-    bool want[6] = {false, false, false, false, false, false};
-    std::atomic<int> ready[6];
-    size_t bytes = 0;
-    int device = 0;
-    RowPrealloc() { for (int k = 0; k < 6; ++k) { ready[k].store(0); err[k] = hipSuccess; } }
-    void start(int n_threads)
-    {
-        for (int t = 0; t < n_threads; ++t)
-            th.emplace_back([this, t, n_threads]() {
-                (void)hipSetDevice(device);
-                for (int k = t; k < 6; k += n_threads) {
-                    if (!want[k]) continue;
-                    const double t0 = rh_now_ms();
-                    err[k] = hipMalloc(&p[k], bytes);
-                    ms[k] = rh_now_ms() - t0;
-                    ready[k].store(1, std::memory_order_release);
-                }
-            });
-    }
-    void wait(int k) const { while (!ready[k].load(std::memory_order_acquire)) std::this_thread::yield(); }
-    ~RowPrealloc()
-    {
-        for (auto &t : th) if (t.joinable()) t.join();
-        for (int k = 0; k < 6; ++k) if (want[k] && p[k]) (void)hipFree(p[k]); // (not taken: the build gave up)
-    }
-};
-
 struct BuildScratch {
-    RowPrealloc *pre = nullptr;
     ScopedBuf arena;
     uint8_t *keys_a = nullptr, *keys_b = nullptr;
     uint32_t *vals_x = nullptr, *vals_b = nullptr;
@@ -458,7 +416,6 @@ struct BuildScratch {
     void *scan_tmp = nullptr;
     size_t scan_tmp_bytes = 0;
     explicit BuildScratch(real_hip_ctx *c) : arena(c) {}
-    ~BuildScratch() { delete pre; }
 };
 
 template <typename K>
@@ -566,15 +523,7 @@ static int index_from_sorted(real_hip_ctx *ctx, BuildScratch &S, int list, const
         uint32_t n_ovf = 0;
         RH_HIP(ctx, hipMemcpyAsync(&n_ovf, S.ostart + nb, 4, hipMemcpyDeviceToHost, ctx->stream));
         RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (S.pre && S.pre->want[list]) { // the helper thread's allocation: wait for it if it is not there yet
-            const double tw = rh_now_ms();
-            S.pre->wait(list);
-            ctx->alloc_exposed_ms += rh_now_ms() - tw;
-            ctx->alloc_ms += S.pre->ms[list]; ctx->alloc_calls++; ctx->alloc_bytes += S.pre->bytes;
-            S.pre->want[list] = false;
-            if (S.pre->err[list] != hipSuccess) return rh_fail(ctx, REAL_HIP_E_NOMEM, "hipMalloc (bucket rows)", S.pre->err[list]);
-            ctx->bkt[list].p = S.pre->p[list]; ctx->bkt[list].cap = S.pre->bytes;
-        } else if ((rc = fit(ctx->bkt[list], (size_t)nb * 128))) return rc;
+        if ((rc = fit(ctx->bkt[list], (size_t)nb * 128))) return rc;
         if ((rc = fit(ctx->ent[list], ((size_t)n_ovf + 1) * sizeof(uint2)))) return rc;
         rh_time_begin(ctx, ctx->stream, REAL_HIP_K_INDEX);
         hipLaunchKernelGGL(rows_fill_kernel, dim3((unsigned)(((uint64_t)nb + 255) / 256)), b1, 0, ctx->stream, (const uint32_t *)d_bkt,
@@ -726,22 +675,6 @@ int rh_index_build_device(real_hip_ctx *ctx, uint64_t first_window, uint64_t max
     for (int attempt = 0;; ++attempt) {
         BuildScratch S(ctx);
         rc = plan_scratch(ctx, S, cnt, l <= 32 ? 4 : 8, true);
-        static const int pre_threads = getenv("REAL_HIP_PREALLOC_THREADS") ? atoi(getenv("REAL_HIP_PREALLOC_THREADS")) : 1;
-        if (!rc && ctx->fine == 3 && cnt && pre_threads > 0) {
-            // bucket rows: their arrays come from a helper thread while the lists are sorted (what a previous block left
-            // and still fits stays; what does not fit goes first, on this thread, before anything runs)
-            const size_t need = ((size_t)1 << ctx->pb) * 128;
-            S.pre = new RowPrealloc();
-            S.pre->bytes = need; S.pre->device = ctx->device;
-            bool any = false;
-            for (int k = 0; k < 6; ++k) {
-                DevBuf &b = ctx->bkt[k];
-                if (b.cap >= need && b.cap <= 2 * need + ((size_t)1 << 20)) continue;
-                rh_release(ctx, b);
-                S.pre->want[k] = true; any = true;
-            }
-            if (any) S.pre->start(pre_threads < 6 ? pre_threads : 6);
-        }
         for (int k = 0; k < 6 && !rc; ++k)
             rc = (l <= 32) ? sort_list<uint32_t>(ctx, S, k, d_wpos, first_window, cnt) : sort_list<uint64_t>(ctx, S, k, d_wpos, first_window, cnt);
         if (!rc) RH_HIP(ctx, hipStreamSynchronize(ctx->stream)); // (before the scratch goes)

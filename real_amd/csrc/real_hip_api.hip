@@ -1,7 +1,6 @@
 // real_hip_api.hip -- the C ABI of include/real_hip.h: context, uploads, staging,
 // launches.  No CPU fallback: every entry point either runs the HIP path or fails.
 #include "real_hip_internal.h"
-#include <cstddef>
 
 #include <chrono>
 #include <cmath>
@@ -37,7 +36,7 @@ int rh_reserve(real_hip_ctx *ctx, DevBuf &b, size_t bytes)
     rh_release(ctx, b);
     const double t0 = rh_now_ms();
     hipError_t e = hipMalloc(&b.p, bytes);
-    if (ctx) { const double dt = rh_now_ms() - t0; ctx->alloc_ms += dt; ctx->alloc_exposed_ms += dt; ctx->alloc_calls++; ctx->alloc_bytes += bytes; }
+    if (ctx) { ctx->alloc_ms += rh_now_ms() - t0; ctx->alloc_calls++; ctx->alloc_bytes += bytes; }
     if (e != hipSuccess) { b.p = nullptr; return rh_fail(ctx, REAL_HIP_E_NOMEM, "hipMalloc", e); }
     b.cap = bytes;
     return REAL_HIP_OK;
@@ -373,14 +372,12 @@ extern "C" int real_hip_build_index_block(real_hip_ctx *ctx, uint64_t first_wind
 
 extern "C" int real_hip_index_build_stats(real_hip_ctx *ctx, real_hip_build_stats *out, int reset)
 {
-    if (!ctx || !out || (out->struct_size != sizeof(real_hip_build_stats) && out->struct_size != offsetof(real_hip_build_stats, alloc_exposed_ms)))
-        return REAL_HIP_E_INVALID;
-    if (out->struct_size == sizeof(real_hip_build_stats)) out->alloc_exposed_ms = ctx->alloc_exposed_ms;
+    if (!ctx || !out || out->struct_size != sizeof(real_hip_build_stats)) return REAL_HIP_E_INVALID;
     out->wall_ms = ctx->build_wall_ms; out->kernel_ms = ctx->k_ms[REAL_HIP_K_INDEX];
     out->alloc_ms = ctx->alloc_ms; out->free_ms = ctx->free_ms;
     out->alloc_bytes = ctx->alloc_bytes; out->alloc_calls = ctx->alloc_calls; out->free_calls = ctx->free_calls;
     if (reset) {
-        ctx->build_wall_ms = ctx->alloc_ms = ctx->free_ms = ctx->alloc_exposed_ms = 0; ctx->alloc_bytes = ctx->alloc_calls = ctx->free_calls = 0;
+        ctx->build_wall_ms = ctx->alloc_ms = ctx->free_ms = 0; ctx->alloc_bytes = ctx->alloc_calls = ctx->free_calls = 0;
         ctx->k_ms[REAL_HIP_K_INDEX] = 0; ctx->k_n[REAL_HIP_K_INDEX] = 0;
     }
     return REAL_HIP_OK;

@@ -165,7 +165,7 @@ struct real_hip_ctx {
     DevBuf raw, raw_count, hit_cnt, big_list, all_cursor, keys_a, keys_b, vals_a, vals_b, sort_tmp, hit_off, s_hits;
 
     // where the wall time of an index build goes (real_hip_index_build_stats)
-    double   alloc_ms = 0, free_ms = 0, build_wall_ms = 0, alloc_exposed_ms = 0; // (exposed: what the calling thread stood waiting for allocations)
+    double   alloc_ms = 0, free_ms = 0, build_wall_ms = 0;
     uint64_t alloc_bytes = 0, alloc_calls = 0, free_calls = 0;
 
     // multi-GPU (gather.hip): an RCCL communicator over the ranks' devices, one process per GPU

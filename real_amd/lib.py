@@ -62,7 +62,7 @@ class RealHipParsed(C.Structure):
 class RealHipBuildStats(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("reserved", C.c_uint32), ("wall_ms", C.c_double), ("kernel_ms", C.c_double),
                 ("alloc_ms", C.c_double), ("free_ms", C.c_double), ("alloc_bytes", C.c_uint64), ("alloc_calls", C.c_uint64),
-                ("free_calls", C.c_uint64), ("alloc_exposed_ms", C.c_double)]
+                ("free_calls", C.c_uint64)]
 
 
 class RealHipCounters(C.Structure):
