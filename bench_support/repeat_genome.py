@@ -77,7 +77,11 @@ def main():
         gi = info[::stride][:k1].contiguous().cpu().numpy().view(np.uint64)
         gs = score[::stride][:k1].contiguous().cpu().numpy()
         parity = bool(np.array_equal(gi, oinfo) and np.array_equal(gs.view(np.uint32), oscore.view(np.uint32)))
-    print(json.dumps({"genome_mbp": args.genome_mbp, "reads": n, "share_in_repeats": args.share, "copies": args.copies,
+    extra = {"work_per_read": {k: ctr[k] / max(ctr["reads"], 1) for k in ("lookups", "probes", "candidates", "seedpass", "hits", "verified")}}
+    if "phase" in os.path.basename(os.environ.get("REAL_HIP_LIB", "")):   # a -DRH_PHASE_TIMING=1 build: the counters are ticks of 10 ns per wave
+        extra = {"per_wave_us": dict(zip(("front", "waiting_for_rows", "decoding", "draining", "staging_qualities", "scoring", "whole_tile"),
+                                         (ctr[k] / max(ctr["reads"] / 64.0, 1) / 100.0 for k in ("lookups", "probes", "candidates", "seedpass", "hits", "verified", "handed_over"))))}
+    print(json.dumps({**extra, "genome_mbp": args.genome_mbp, "reads": n, "share_in_repeats": args.share, "copies": args.copies,
                       "ms_per_step": dt / args.steps * 1e3, "reads_per_s": n * args.steps / dt,
                       "lane_kernel_ms": ms / max(ln, 1), "wave_kernel_ms": rms / max(rn, 1),
                       "table_kind": m.table_kind, "prefix_bits": m.prefix_bits, "at": args.at, "fragments": args.fragments, "n_runs": args.n_runs, "parity_with_cpu_port": parity, "checked_reads": args.check, "handed_over_frac": ctr["handed_over"] / max(ctr["reads"], 1),

@@ -546,19 +546,25 @@ static int index_from_sorted(real_hip_ctx *ctx, BuildScratch &S, int list, const
     return REAL_HIP_OK;
 }
 
+template <typename K>
+static int sort_list(real_hip_ctx *ctx, BuildScratch &S, int list, const uint32_t *d_wpos, uint64_t first_window, uint64_t n, bool uploaded = false);
+
 // host-built form (real_hip_set_index_block): the six sorted lists are uploaded one after the other through the scratch
 int rh_index_from_host_lists(real_hip_ctx *ctx, uint64_t n, const void *const sign[6], const uint32_t *const pos[6], unsigned sig_bytes)
 {
     const double t0 = rh_now_ms();
     BuildScratch S(ctx);
-    int rc = plan_scratch(ctx, S, n, sig_bytes, false);
+    const bool rows = ctx->fine == 3; // bucket rows: the lists are sorted once more, by the mixed signature (sort_list)
+    int rc = plan_scratch(ctx, S, n, sig_bytes, rows);
     if (rc) return rc;
     for (int k = 0; k < 6; ++k) {
         if (n) {
             RH_HIP(ctx, hipMemcpyAsync(S.keys_b, sign[k], n * sig_bytes, hipMemcpyHostToDevice, ctx->stream));
             RH_HIP(ctx, hipMemcpyAsync(S.vals_b, pos[k], n * 4, hipMemcpyHostToDevice, ctx->stream));
         }
-        if ((rc = index_from_sorted(ctx, S, k, S.keys_b, S.vals_b, n, sig_bytes))) return rc;
+        if (rows) rc = sig_bytes == 4 ? sort_list<uint32_t>(ctx, S, k, nullptr, 0, n, true) : sort_list<uint64_t>(ctx, S, k, nullptr, 0, n, true);
+        else rc = index_from_sorted(ctx, S, k, S.keys_b, S.vals_b, n, sig_bytes);
+        if (rc) return rc;
     }
     RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     rh_time_resolve(ctx);
@@ -592,32 +598,51 @@ __global__ void iota_kernel(uint32_t *out, uint64_t first, uint64_t n)
     if (i < n) out[i] = (uint32_t)(first + i);
 }
 
-// list k signature of the window at wpos[j]
+// list k signature of the window at wpos[j]; mix: the sort key of the bucket rows (rh_mix32 / rh_mix64)
+template <typename K>
+__device__ __forceinline__ K mixed_key(K v, uint32_t l) { return sizeof(K) == 4 ? (K)rh_mix32((uint32_t)v, l) : (K)rh_mix64((uint64_t)v, l); }
 template <typename K>
 __global__ void keys_kernel(const uint64_t *__restrict__ T, const uint32_t *__restrict__ wpos, uint64_t n, uint32_t l,
-                            int list, K *__restrict__ keys)
+                            int list, bool mix, K *__restrict__ keys)
 {
     uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    keys[j] = (K)window_signature(T, wpos[j], l, list);
+    const K v = (K)window_signature(T, wpos[j], l, list);
+    keys[j] = mix ? mixed_key<K>(v, l) : v;
+}
+template <typename K>
+__global__ void mix_keys_kernel(K *__restrict__ keys, uint64_t n, uint32_t l)
+{
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) keys[j] = mixed_key<K>(keys[j], l);
 }
 
 // d_wpos: the window starts of the block in ascending order, or null = every window from first_window on (no N in the text)
+// uploaded: the list is in (S.keys_b, S.vals_b) already, sorted by signature (host-built lists for bucket rows): only
+// mixed and sorted again
 template <typename K>
-static int sort_list(real_hip_ctx *ctx, BuildScratch &S, int list, const uint32_t *d_wpos, uint64_t first_window, uint64_t n)
+static int sort_list(real_hip_ctx *ctx, BuildScratch &S, int list, const uint32_t *d_wpos, uint64_t first_window, uint64_t n, bool uploaded)
 {
     const uint32_t l = ctx->prm.seedl;
     const void *d_sign = S.keys_b;
     const uint32_t *d_pos = S.vals_b;
+    const bool mix = ctx->fine == 3;
     if (n) {
         rh_time_begin(ctx, ctx->stream, REAL_HIP_K_INDEX);
-        // the values of the sort: a fresh copy of the window starts for every list (the sort clobbers both buffers)
-        if (d_wpos) RH_HIP(ctx, hipMemcpyAsync(S.vals_x, d_wpos, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        else hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, S.vals_x, first_window, n);
-        hipLaunchKernelGGL(keys_kernel<K>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                           (const uint64_t *)ctx->text.p, (const uint32_t *)S.vals_x, n, l, list, (K *)S.keys_a);
+        const dim3 grid((unsigned)((n + 255) / 256)), block(256);
         rocprim::double_buffer<K> keys((K *)S.keys_a, (K *)S.keys_b);
         rocprim::double_buffer<uint32_t> vals(S.vals_x, S.vals_b);
+        if (uploaded) {
+            hipLaunchKernelGGL(mix_keys_kernel<K>, grid, block, 0, ctx->stream, (K *)S.keys_b, n, l);
+            keys = rocprim::double_buffer<K>((K *)S.keys_b, (K *)S.keys_a);
+            vals = rocprim::double_buffer<uint32_t>(S.vals_b, S.vals_x);
+        } else {
+            // the values of the sort: a fresh copy of the window starts for every list (the sort clobbers both buffers)
+            if (d_wpos) RH_HIP(ctx, hipMemcpyAsync(S.vals_x, d_wpos, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            else hipLaunchKernelGGL(iota_kernel, grid, block, 0, ctx->stream, S.vals_x, first_window, n);
+            hipLaunchKernelGGL(keys_kernel<K>, grid, block, 0, ctx->stream, (const uint64_t *)ctx->text.p, (const uint32_t *)S.vals_x, n, l, list, mix,
+                               (K *)S.keys_a);
+        }
         size_t tmp = S.sort_tmp_bytes;
         RH_HIP(ctx, sort_pairs<K>(S.sort_tmp, tmp, keys, vals, n, l, ctx->stream));
         rh_time_end(ctx, ctx->stream);
@@ -922,9 +947,21 @@ int rh_index_export(real_hip_ctx *ctx, int list, void *h_sign, uint32_t *h_pos)
     if ((rc = rh_reserve(ctx, ctx->vals_a, n * 4))) return rc;
     ScopedBuf unpacked(ctx); // bucket rows: the entries in list order first
     const uint2 *d_ent = (const uint2 *)ctx->ent[list].p;
-    if (ctx->fine == 3) {
-        if ((rc = rh_reserve(ctx, unpacked, n * sizeof(uint2)))) return rc;
-        if ((rc = rh_rows_unpack(ctx, list, (uint2 *)unpacked.p, nullptr))) return rc;
+    const bool rows = ctx->fine == 3;
+    size_t sort_tmp = 0;
+    if (rows) {
+        // ... and that order is the one of the mixed signatures (real_hip_internal.h: rh_mix32): signatures and positions are
+        // sorted back into the reference's list order (stable: equal signatures are together and in ascending position
+        // already).  The unpacked entries are dead once the signatures are computed: their room is the sort's other buffer.
+        rocprim::double_buffer<uint32_t> v(nullptr, nullptr);
+        hipError_t e;
+        if (sb == 4) { rocprim::double_buffer<uint32_t> k(nullptr, nullptr); e = sort_pairs<uint32_t>(nullptr, sort_tmp, k, v, n, l, ctx->stream); }
+        else { rocprim::double_buffer<uint64_t> k(nullptr, nullptr); e = sort_pairs<uint64_t>(nullptr, sort_tmp, k, v, n, l, ctx->stream); }
+        if (e != hipSuccess) return rh_fail(ctx, REAL_HIP_E_DEVICE, "radix sort (size query)", e);
+        const size_t room = n * (sb + 4) > n * sizeof(uint2) ? n * (sb + 4) : n * sizeof(uint2);
+        if ((rc = rh_reserve(ctx, unpacked, room))) return rc;
+        if ((rc = rh_reserve(ctx, ctx->sort_tmp, sort_tmp ? sort_tmp : 8))) return rc;
+        if ((rc = rh_rows_unpack(ctx, list, (uint2 *)unpacked.p, nullptr))) return rc; // (uses ctx->sort_tmp for its scan: before the sort)
         d_ent = (const uint2 *)unpacked.p;
     }
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
@@ -935,8 +972,26 @@ int rh_index_export(real_hip_ctx *ctx, int list, void *h_sign, uint32_t *h_pos)
         hipLaunchKernelGGL(export_kernel<uint64_t>, grid, block, 0, ctx->stream, d_ent,
                            (const uint64_t *)ctx->text.p, n, l, list, (uint64_t *)ctx->keys_a.p, (uint32_t *)ctx->vals_a.p);
     RH_HIP(ctx, hipGetLastError());
-    if (h_sign) RH_HIP(ctx, hipMemcpyAsync(h_sign, ctx->keys_a.p, n * sb, hipMemcpyDeviceToHost, ctx->stream));
-    if (h_pos) RH_HIP(ctx, hipMemcpyAsync(h_pos, ctx->vals_a.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    const void *d_sign = ctx->keys_a.p;
+    const uint32_t *d_pos = (const uint32_t *)ctx->vals_a.p;
+    if (rows) {
+        if ((rc = rh_reserve(ctx, ctx->sort_tmp, sort_tmp ? sort_tmp : 8))) return rc; // (rh_rows_unpack may have left a smaller one)
+        uint8_t *alt = (uint8_t *)unpacked.p;
+        rocprim::double_buffer<uint32_t> vals((uint32_t *)ctx->vals_a.p, (uint32_t *)(alt + n * sb));
+        size_t tmp = sort_tmp;
+        if (sb == 4) {
+            rocprim::double_buffer<uint32_t> keys((uint32_t *)ctx->keys_a.p, (uint32_t *)alt);
+            RH_HIP(ctx, sort_pairs<uint32_t>(ctx->sort_tmp.p, tmp, keys, vals, n, l, ctx->stream));
+            d_sign = keys.current();
+        } else {
+            rocprim::double_buffer<uint64_t> keys((uint64_t *)ctx->keys_a.p, (uint64_t *)alt);
+            RH_HIP(ctx, sort_pairs<uint64_t>(ctx->sort_tmp.p, tmp, keys, vals, n, l, ctx->stream));
+            d_sign = keys.current();
+        }
+        d_pos = vals.current();
+    }
+    if (h_sign) RH_HIP(ctx, hipMemcpyAsync(h_sign, d_sign, n * sb, hipMemcpyDeviceToHost, ctx->stream));
+    if (h_pos) RH_HIP(ctx, hipMemcpyAsync(h_pos, d_pos, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     RH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return REAL_HIP_OK;
 }

@@ -767,7 +767,11 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
         const uint64_t sc_ = ((xc < 2 ? MA : MB) >> (32 * (1 - (xc & 1)))) & 0xffffffffull;
         return (sa_ << bb) | sc_;
     };
-    auto bucket_of = [&](int la) { return wide ? (uint32_t)(sig_wide(la) >> a.ix.pshift) : (sig_of(la) >> gbits); };
+    // the rows are addressed by the MIXED signature (real_hip_internal.h: rh_mix32 / rh_mix64): row = its leading bits,
+    // key group = the bits below; the partner key of an entry is plain
+    auto msig_of = [&](int la) { return rh_mix32(sig_of(la), a.l); };
+    auto msig_wide = [&](int la) { return rh_mix64(sig_wide(la), a.l); };
+    auto bucket_of = [&](int la) { return wide ? (uint32_t)(msig_wide(la) >> a.ix.pshift) : (msig_of(la) >> gbits); };
     uint32_t qn = 0, q_last = 0, q_lastla = 0; // queue fill; position and list bits of the entry pushed last
     uint4 va0, va1, va2, va3, va4, va5, va6, va7; // (eight scalars, not an array: the array went through scratch memory)
     uint32_t *bkx = reinterpret_cast<uint32_t *>(stg + BKX_OFF);
@@ -852,10 +856,10 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
         bool e_ovf = false;
         uint32_t g, r; // key group; what an entry's key is compared with (narrow: leading pbits of s_b; wide: the 32-bit key)
         if (!wide) {
-            g = sig_of(la) & ((1u << gbits) - 1);
+            g = msig_of(la) & ((1u << gbits) - 1);
             r = sig_of(5 - la) >> (a.l - pbits);
         } else {
-            r = (uint32_t)(sig_wide(la) >> a.ix.fshift);
+            r = (uint32_t)(msig_wide(la) >> a.ix.fshift);
             g = r >> 28;
         }
         if (mine) {
@@ -909,20 +913,13 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
         // (the lane's last queue entry is kept in registers: for it nothing is read back).  A lane that needs
         // more than MQR queue slots for one strand (repeat-rich loci only) hands its read over: the queues are drained
         // once, behind the lists, where the registers that hold the rows in flight are free again.
-        while (__any(e_j < e_cnt)) {
-            const bool step = e_j < e_cnt;
-            uint32_t pos, x;
-            if (!e_ovf) { // 6 bytes at halfword 4 + 3 * (e_base + e_j) of the row
-                const uint32_t h = step ? 4 + 3 * (e_base + e_j) : 4u;
-                const uint32_t d0 = row(h >> 1), d1 = row((h >> 1) + 1);
-                const uint32_t key = (h & 1) ? (d0 >> 16) : (d0 & 0xffffu);
-                pos = (h & 1) ? d1 : ((d0 >> 16) | (d1 << 16));
-                x = key ^ rk;
-            } else {
-                const uint2 e = step ? a.ix.ent[la][e_base + e_j] : make_uint2(0u, 0u);
-                pos = e.y;
-                x = wide ? (e.x ^ r) : ((e.x & pmask) ^ r);
-            }
+        // A lane whose row is complex finds its entries in the overflow array: their first two are requested here and looked
+        // at behind the loop of the lanes with simple rows -- the round trip is hidden behind that loop instead of standing in
+        // front of every step of the whole wave (with a skewed base composition nearly every wave has such a lane in every
+        // list).  A lane is of one kind for the whole list, so the order of its own entries is what it was.
+        U64x2 pre = {0ull, 0ull};
+        if (e_ovf && e_cnt) pre = load2(reinterpret_cast<const uint64_t *>(a.ix.ent[la] + e_base)); // (two entries; the array is padded by one)
+        auto take = [&](bool step, uint32_t pos, uint32_t x) {
             // seed popcount filter (match.hpp:386) on the partner symbols the entry carries: more than seedkmax
             // known mismatches => rejected without touching the text (exact: the full count can only be larger)
             bool pass = step && (wide ? (x == 0u) : (__popc(((x >> 1) | x) & 0x55555555u) <= a.seedkmax));
@@ -936,6 +933,20 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
             const uint32_t lav = (merge ? q_lastla : 0u) | (1u << la);
             if (pass) { q_pos[slot * 64] = pos; q_la[slot * 64] = (uint8_t)lav; q_last = pos; q_lastla = lav; qn = slot + 1; }
             e_j += step ? 1u : 0u;
+        };
+        while (__any(!e_ovf && e_j < e_cnt)) { // simple rows: 6 bytes at halfword 4 + 3 * (e_base + e_j) of the row
+            const bool step = !e_ovf && e_j < e_cnt;
+            const uint32_t h = step ? 4 + 3 * (e_base + e_j) : 4u;
+            const uint32_t d0 = row(h >> 1), d1 = row((h >> 1) + 1);
+            const uint32_t key = (h & 1) ? (d0 >> 16) : (d0 & 0xffffu);
+            take(step, (h & 1) ? d1 : ((d0 >> 16) | (d1 << 16)), key ^ rk);
+        }
+        while (__any(e_ovf && e_j < e_cnt)) { // complex rows: {key, pos} in the overflow array
+            const bool step = e_ovf && e_j < e_cnt;
+            uint2 e = make_uint2((uint32_t)pre.a, (uint32_t)(pre.a >> 32));
+            if (e_j == 1) e = make_uint2((uint32_t)pre.b, (uint32_t)(pre.b >> 32));
+            if (step && e_j >= 2) e = a.ix.ent[la][e_base + e_j];
+            take(step, e.y, wide ? (e.x ^ r) : ((e.x & pmask) ^ r));
         }
 #if RH_PHASE_TIMING
         s.tD += PH_NOW() - ph1;

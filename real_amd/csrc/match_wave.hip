@@ -75,16 +75,18 @@ __device__ __forceinline__ WaveRange wave_lookup(const MatchArgs &a, uint64_t sh
         R.lo = first; R.cnt = x - first; R.key = f; R.mode = 0;
         return R;
     }
-    // bucket rows
+    // bucket rows: addressed by the mixed signature (real_hip_internal.h: rh_mix32 / rh_mix64)
     const bool wide = pbits == 0;
     uint32_t g, bucket;
     if (!wide) {
         const uint32_t gbits = a.ix.fbits;
-        bucket = (uint32_t)sa >> gbits; g = (uint32_t)sa & ((1u << gbits) - 1);
+        const uint32_t msa = rh_mix32((uint32_t)sa, l);
+        bucket = msa >> gbits; g = msa & ((1u << gbits) - 1);
         R.key = R.partner;
     } else {
-        bucket = prefix;
-        R.key = (uint32_t)(sa >> a.ix.fshift);
+        const uint64_t msa = rh_mix64(sa, l);
+        bucket = (uint32_t)(msa >> a.ix.pshift);
+        R.key = (uint32_t)(msa >> a.ix.fshift);
         g = R.key >> 28;
     }
     const uint32_t *row = a.ix.bkt[la] + (uint64_t)bucket * 32;
@@ -293,11 +295,130 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
             const uint32_t q = lane < 12 ? lane : 0u;
             RL = wave_lookup(a, q >= 6 ? rhi : shi, q >= 6 ? rlo : slo, (int)(q >= 6 ? q - 6 : q));
         }
-        for (int inv = 0; inv < 2; ++inv) {
-            if (inv) { shi = rhi; slo = rlo; } // transposed pattern, Pattern.hpp:105-128
+        // one candidate of list la of strand inv, every lane for its own: entry -> partner filter -> seed window on the text ->
+        // position / fragment / N checks -> Hamming distance (no score yet).  R, inv, la may differ from lane to lane.
+        auto candidate = [&](const WaveRange &R, uint32_t i, bool cand, uint32_t inv, uint32_t la, uint32_t &pos, uint32_t &total, uint32_t &frag,
+                             uint32_t &first) -> bool {
+            const uint32_t xa = (0x940u >> (2 * la)) & 3u, xc = (0xfb9u >> (2 * la)) & 3u;
+            const uint64_t hi_ = inv ? rhi : shi, lo_ = inv ? rlo : slo;
             const uint64_t *const cur = inv ? sR : sO;
-            uint32_t nmemo = 0; // scored locations of this strand (wave-uniform)
             const uint32_t so = inv ? (patl - l) : 0u; // RestMatch::getMatchOffset, RestMatch.hpp:84-89
+            uint32_t rpos = 0;
+            if (cand) {
+                if (R.mode == 1 || R.mode == 2) { // 6 bytes at halfword 4 + 3 * (lo + i) of the row
+                    const uint32_t h = 4 + 3 * (R.lo + i);
+                    const uint32_t d0 = R.row[h >> 1], d1 = R.row[(h >> 1) + 1];
+                    const uint32_t key = (h & 1) ? (d0 >> 16) : (d0 & 0xffffu);
+                    rpos = (h & 1) ? d1 : ((d0 >> 16) | (d1 << 16));
+                    const uint32_t x = key ^ (R.key >> (pbits - p16));
+                    cand = R.mode == 2 ? (key == rh_fp16(R.key)) : (__popc(((x >> 1) | x) & 0x5555u) <= a.seedkmax);
+                } else {
+                    const uint2 e = R.E[R.lo + i];
+                    rpos = e.y;
+                    if (R.mode == 4) cand = e.x == R.key;
+                    else if (R.mode == 0 && !pbits) cand = true; // (the bounds were found on the whole key)
+                    else {
+                        // seed popcount filter (match.hpp:386) on the partner symbols the entry carries: more than
+                        // seedkmax known mismatches => rejected without touching the text (exact: the full count can
+                        // only be larger)
+                        if (R.mode == 0) cC++; // a member of the reference's equal range
+                        const uint32_t x = (e.x & pmask) ^ R.partner;
+                        cand = __popc(((x >> 1) | x) & 0x55555555u) <= a.seedkmax;
+                    }
+                }
+            }
+            if (!cand) return false;
+            const uint64_t wi0 = rpos >> 5;
+            const U64x2 tt = load2(T + wi0);
+            const uint64_t t2 = (l > 32) ? T[wi0 + 2] : 0ull;
+            const unsigned sh0 = 2u * (rpos & 31);
+            const uint64_t xhi = extract_bits(tt.a, tt.b, t2, sh0, l) ^ hi_;
+            const uint64_t xlo = extract_bits(tt.a, tt.b, t2, sh0 + l, l) ^ lo_;
+            const uint64_t dhi = ((xhi >> 1) | xhi) & M55, dlo = ((xlo >> 1) | xlo) & M55;
+            const uint32_t k0 = __popcll(dhi >> bb), k1 = __popcll(dhi & mb), k2 = __popcll(dlo >> bb), k3 = __popcll(dlo & mb);
+            const bool z0 = !k0, z1 = !k1, z2 = !k2, z3 = !k3;
+            // a member of list la's equal range iff both segments the list is keyed on are mismatch free
+            const bool za = xa == 0 ? z0 : xa == 1 ? z1 : z2, zc = xc == 1 ? z1 : xc == 2 ? z2 : z3;
+            bool ok = za && zc;
+            if (ok && !pbits) cC++;
+            const uint32_t seedk = k0 + k1 + k2 + k3; // = diffcountpair(s_b, list_b[p->ptr].sign), match.hpp:386
+            ok = ok && seedk <= a.seedkmax;
+            if (ok) cS++;
+            ok = ok && rpos >= so; // match.hpp:393
+            if (ok) {
+                pos = rpos - so;
+                cV++;
+                ok = frag_valid(a.t, pos, patl, frag) && !(a.t.has_wild && !wild_free(a.t.wild, pos, patl));
+            }
+            if (!ok) return false;
+            // Hamming distance of the whole oriented read against text[pos, pos+patl)
+            // = seedk + RestMatch::computeDistance (RestMatch.hpp:39-81)
+            total = long_distance(T, cur, pos, nw, lastmask, a.totalkmax);
+            if (total > a.totalkmax) return false;
+            cH++; // one updater::update call per list, match.hpp:411
+            first = (z0 && z1) ? 0u : (z0 && z2) ? 1u : (z0 && z3) ? 2u : (z1 && z2) ? 3u : (z1 && z3) ? 4u : 5u;
+            return true;
+        };
+        const uint8_t *const qrow = !a.b.qual ? nullptr : (q_lds ? (const uint8_t *)qst + 16 : a.b.qual + o0);
+        // ---- few candidates (a read on a handful of copies of a locus -- what most of the reads that come here are): all twelve
+        // equal ranges in ONE round, lane = (strand, list, entry) in the canonical order.  One chain of dependent loads (entry
+        // -> text -> verdict -> score) per read instead of twelve, and the survivors are folded in lane order = strand, list,
+        // entry = the reference's order of update() calls.  (Without scores the 12-call driver may skip lists 1..5 of a strand
+        // after list 0, matchUniqueImplementation.cpp:434-436: that mode walks the lists one by one below.)
+        uint32_t c_mine = lane < 12 ? RL.cnt : 0u, c_before = 0, c_total = 0;
+        {
+            uint32_t run = 0;
+#pragma unroll
+            for (int q = 0; q < 12; ++q) {
+                const uint32_t c = (uint32_t)__shfl((int)c_mine, q);
+                if ((uint32_t)q == lane) c_before = run;
+                run += c;
+            }
+            c_total = run;
+        }
+        if ((SCORES || ALL) && c_total <= 64u) {
+            // the (strand, list) whose range lane `lane` falls into: the last q with before[q] <= lane
+            uint32_t src = 0;
+#pragma unroll
+            for (int q = 1; q < 12; ++q)
+                if ((uint32_t)__shfl((int)c_before, q) <= lane) src = (uint32_t)q;
+            WaveRange R;
+            {
+                const uint64_t e = (uint64_t)(uintptr_t)RL.E, w = (uint64_t)(uintptr_t)RL.row;
+                R.E = (const uint2 *)(uintptr_t)(((uint64_t)(uint32_t)__shfl((int)(e >> 32), (int)src) << 32) | (uint32_t)__shfl((int)e, (int)src));
+                R.row = (const uint32_t *)(uintptr_t)(((uint64_t)(uint32_t)__shfl((int)(w >> 32), (int)src) << 32) | (uint32_t)__shfl((int)w, (int)src));
+                R.lo = (uint32_t)__shfl((int)RL.lo, (int)src); R.cnt = (uint32_t)__shfl((int)RL.cnt, (int)src); R.key = (uint32_t)__shfl((int)RL.key, (int)src);
+                R.mode = (uint32_t)__shfl((int)RL.mode, (int)src); R.partner = (uint32_t)__shfl((int)RL.partner, (int)src); R.counted = (uint32_t)__shfl((int)RL.counted, (int)src);
+            }
+            if (lane < 12) { cL++; cP += RL.cnt; cC += RL.counted; }
+            const uint32_t inv = src >= 6 ? 1u : 0u, la = src - 6 * inv;
+            const uint32_t i = lane - (uint32_t)__shfl((int)c_before, (int)src);
+            uint32_t pos = 0, total = 0, frag = 0, first = 0;
+            const bool hit = candidate(R, i, lane < c_total, inv, la, pos, total, frag, first);
+            float sc = 1.0f; // ComputeScore<...,false>, ComputeScore.hpp:31-45
+            // (a location reached through several lists is scored by each of its lanes: the lanes run the loop together anyway)
+            if (SCORES && hit) sc = long_score(sLL, T, inv ? sR : sO, pos, patl, qrow, inv);
+            if (ALL) {
+                // unifyMatches (matchAllImplementation.cpp:150-161) removes exact duplicates: a (strand, pos) is kept
+                // from the first list whose two segments are mismatch free
+                const bool keep = hit && first == la;
+                if (keep) {
+                    const unsigned long long slot = wave_append_slot(a.raw_count); // ballot + prefix popcount, one atomic
+                    if (slot < a.raw_cap) a.raw[slot] = make_uint4((uint32_t)r, pos, __float_as_uint(sc), total | (inv << 8) | (frag << 16));
+                }
+                nhit += (uint32_t)__popcll(__ballot(keep));
+            } else {
+                unsigned long long hm = __ballot(hit);
+                while (hm) { // UpdateUniqueInfo::update in candidate order; the record is wave-uniform
+                    const int j = __ffsll((long long)hm) - 1;
+                    hm &= hm - 1;
+                    fold_update<SCORES>(__shfl((int)inv, j) != 0, a.t.fileid, (uint32_t)__shfl((int)pos, j), (unsigned)__shfl((int)total, j), __shfl(sc, j), eps,
+                                        (unsigned)__shfl((int)frag, j), info, iscore);
+                }
+            }
+        } else
+        for (int inv = 0; inv < 2; ++inv) {
+            uint32_t nmemo = 0; // scored locations of this strand (wave-uniform)
 #pragma unroll 1
             for (int la = 0; la < 6; ++la) {
                 if (!ALL && !SCORES && la == 1) {
@@ -315,76 +436,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
                     R.mode = (uint32_t)__shfl((int)RL.mode, src); R.partner = (uint32_t)__shfl((int)RL.partner, src); R.counted = (uint32_t)__shfl((int)RL.counted, src);
                 }
                 if (lane == 0) { cL++; cP += R.cnt; cC += R.counted; }
-                const uint32_t xa = (0x940u >> (2 * la)) & 3u, xc = (0xfb9u >> (2 * la)) & 3u;
 #pragma unroll 1
                 for (uint32_t c0 = 0; c0 < R.cnt; c0 += 64) {
                     const uint32_t i = c0 + lane;
-                    bool cand = i < R.cnt;
-                    uint32_t rpos = 0;
-                    if (cand) {
-                        if (R.mode == 1 || R.mode == 2) { // 6 bytes at halfword 4 + 3 * (lo + i) of the row
-                            const uint32_t h = 4 + 3 * (R.lo + i);
-                            const uint32_t d0 = R.row[h >> 1], d1 = R.row[(h >> 1) + 1];
-                            const uint32_t key = (h & 1) ? (d0 >> 16) : (d0 & 0xffffu);
-                            rpos = (h & 1) ? d1 : ((d0 >> 16) | (d1 << 16));
-                            const uint32_t x = key ^ (R.key >> (pbits - p16));
-                            cand = R.mode == 2 ? (key == rh_fp16(R.key)) : (__popc(((x >> 1) | x) & 0x5555u) <= a.seedkmax);
-                        } else {
-                            const uint2 e = R.E[R.lo + i];
-                            rpos = e.y;
-                            if (R.mode == 4) cand = e.x == R.key;
-                            else if (R.mode == 0 && !pbits) cand = true; // (the bounds were found on the whole key)
-                            else {
-                                // seed popcount filter (match.hpp:386) on the partner symbols the entry carries: more than
-                                // seedkmax known mismatches => rejected without touching the text (exact: the full count can
-                                // only be larger)
-                                if (R.mode == 0) cC++; // a member of the reference's equal range
-                                const uint32_t x = (e.x & pmask) ^ R.partner;
-                                cand = __popc(((x >> 1) | x) & 0x55555555u) <= a.seedkmax;
-                            }
-                        }
-                    }
-                    // ---- seed window on the text, filters, Hamming distance: every lane for its own candidate
-                    bool hit = false, scored = false;
                     uint32_t pos = 0, total = 0, frag = 0, first = 0;
+                    const bool hit = candidate(R, i, i < R.cnt, (uint32_t)inv, (uint32_t)la, pos, total, frag, first);
+                    bool scored = false;
                     float sc = 1.0f; // ComputeScore<...,false>, ComputeScore.hpp:31-45
-                    if (cand) {
-                        const uint64_t wi0 = rpos >> 5;
-                        const U64x2 tt = load2(T + wi0);
-                        const uint64_t t2 = (l > 32) ? T[wi0 + 2] : 0ull;
-                        const unsigned sh0 = 2u * (rpos & 31);
-                        const uint64_t xhi = extract_bits(tt.a, tt.b, t2, sh0, l) ^ shi;
-                        const uint64_t xlo = extract_bits(tt.a, tt.b, t2, sh0 + l, l) ^ slo;
-                        const uint64_t dhi = ((xhi >> 1) | xhi) & M55, dlo = ((xlo >> 1) | xlo) & M55;
-                        const uint32_t k0 = __popcll(dhi >> bb), k1 = __popcll(dhi & mb), k2 = __popcll(dlo >> bb), k3 = __popcll(dlo & mb);
-                        const bool z0 = !k0, z1 = !k1, z2 = !k2, z3 = !k3;
-                        // a member of list la's equal range iff both segments the list is keyed on are mismatch free
-                        const bool za = xa == 0 ? z0 : xa == 1 ? z1 : z2, zc = xc == 1 ? z1 : xc == 2 ? z2 : z3;
-                        bool ok = za && zc;
-                        if (ok && !pbits) cC++;
-                        const uint32_t seedk = k0 + k1 + k2 + k3; // = diffcountpair(s_b, list_b[p->ptr].sign), match.hpp:386
-                        ok = ok && seedk <= a.seedkmax;
-                        if (ok) cS++;
-                        ok = ok && rpos >= so; // match.hpp:393
-                        if (ok) {
-                            pos = rpos - so;
-                            cV++;
-                            ok = frag_valid(a.t, pos, patl, frag) && !(a.t.has_wild && !wild_free(a.t.wild, pos, patl));
-                        }
-                        if (ok) {
-                            // Hamming distance of the whole oriented read against text[pos, pos+patl)
-                            // = seedk + RestMatch::computeDistance (RestMatch.hpp:39-81)
-                            total = long_distance(T, cur, pos, nw, lastmask, a.totalkmax);
-                            if (total <= a.totalkmax) {
-                                hit = true;
-                                cH++; // one updater::update call per list, match.hpp:411
-                                if (SCORES && !memo_score(sMemoPos[threadIdx.x >> 6], sMemoSc[threadIdx.x >> 6], nmemo, pos, sc)) {
-                                    sc = long_score(sLL, T, cur, pos, patl, !a.b.qual ? nullptr : (q_lds ? (const uint8_t *)qst + 16 : a.b.qual + o0), (uint32_t)inv);
-                                    scored = true;
-                                }
-                                first = (z0 && z1) ? 0u : (z0 && z2) ? 1u : (z0 && z3) ? 2u : (z1 && z2) ? 3u : (z1 && z3) ? 4u : 5u;
-                            }
-                        }
+                    if (SCORES && hit && !memo_score(sMemoPos[threadIdx.x >> 6], sMemoSc[threadIdx.x >> 6], nmemo, pos, sc)) {
+                        sc = long_score(sLL, T, inv ? sR : sO, pos, patl, qrow, (uint32_t)inv);
+                        scored = true;
                     }
                     if (SCORES) { // the scores computed in this round are kept for the lists to come (the same window, the same score)
                         const unsigned long long sm = __ballot(scored);

@@ -59,6 +59,20 @@ static inline __host__ __device__ uint32_t rh_fp11(uint32_t key) { return (key *
 // 16-bit fingerprint of the other 28
 static inline __host__ __device__ uint32_t rh_fp16(uint32_t key) { return ((key & 0x0fffffffu) * 0x9E3779B1u) >> 16; }
 
+// Bucket rows are addressed through a bijection of the signature space: mixed = sign * odd constant mod 2^seedl.  The row
+// of a signature is the leading bits of the MIXED value, its key group the bits below.  A genome's signatures are far from
+// uniform when its base composition is skewed (60 % A+T, the human genome's share: the 16 signature values that share a
+// 14-base prefix rich in A/T hold ten times the mean, a third of all entries sits in rows that overflow); the leading bits
+// of the product depend on every bit of the signature, so a row collects 16 unrelated signature values and the loads
+// concentrate around the mean (2.7 % of the entries in overflowing rows at 60 % A+T).  Being a
+// bijection it keeps the layout exact: (row, key group) <-> one signature value, the entries of a group are the
+// reference's equal range in its order (the sort is stable: ascending position inside equal signatures; the order of
+// DIFFERENT signatures in the device list is the mixed one, real_hip_index_export sorts it back).
+#define RH_MIX32 0x9E3779B1u
+#define RH_MIX64 0x9E3779B97F4A7C15ull
+static inline __host__ __device__ uint32_t rh_mix32(uint32_t sign, uint32_t l) { return (sign * RH_MIX32) & (l >= 32 ? 0xffffffffu : ((1u << l) - 1u)); }
+static inline __host__ __device__ uint64_t rh_mix64(uint64_t sign, uint32_t l) { return (sign * RH_MIX64) & (l >= 64 ? ~0ull : ((1ull << l) - 1ull)); }
+
 // entry geometry shared by the index build and the matcher
 static inline void rh_index_geometry(uint32_t l, uint32_t pb, uint32_t *pshift, uint32_t *fshift, uint32_t *fbits, uint32_t *pbits)
 {
