@@ -234,8 +234,12 @@ int real_hip_match_all(real_hip_ctx *ctx, const real_hip_batch *b,
  * matchAllImplementation.cpp:451-535).  Bootstrap: rank 0 calls real_hip_comm_id and hands the 128 bytes to the other
  * ranks by the launcher's own means (MPI_Bcast, a file, the rendezvous store); every rank then calls
  * real_hip_comm_init on its ctx.  All array arguments are DEVICE pointers of the ctx's device; the receive arrays
- * matter on the root only.  Counts travel first (every rank learns every rank's sizes and the root's capacities, so a
- * too small receive array is REAL_HIP_E_OVERFLOW on ALL ranks, with the needed sizes in *n_..._all), then the payload.
+ * matter on the root only.  Counts travel first: every rank learns every rank's sizes, the root's capacities, which
+ * receive arrays the root was given, and whether a rank found something wrong on its own side (a null send array, a
+ * scratch buffer it could not reserve).  Every decision to give up is taken from those exchanged tuples alone -- a too
+ * small receive array is REAL_HIP_E_OVERFLOW on ALL ranks (with the needed sizes in *n_..._all), null receive arrays on
+ * the root or a failed peer are the same error on ALL ranks -- and is taken before any rank posts a send or a receive:
+ * nobody is left waiting for a root that has returned.  Then the payload.  `root` must be the same valid rank everywhere.
  * A single process that drives several GPUs through several ctx (real -gpus N) needs none of this: its calls write
  * the shards' results into the caller's host arrays directly.                                                       */
 #define REAL_HIP_COMM_ID_BYTES 128

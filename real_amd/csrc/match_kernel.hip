@@ -65,17 +65,28 @@ __host__ __device__ constexpr uint32_t stg_bytes(int W, int TK) { return TK >= 3
 #define ROWBUF_OFF (MQR * 64u * 5u)
 #define BKX_OFF (ROWBUF_OFF + 64u * 128u) /* 64 bucket numbers, transposed for the piece loaders */
 static_assert(BKX_OFF + 256u <= stg_bytes(4, 3) && ROWBUF_OFF % 16 == 0 && QUEUE_BYTES % 16 == 0, "row staging fits the wave's LDS region");
+// The second pass (bucket rows; scores on or matchAll): the reads whose locations or queue entries outgrew a lane of the first
+// pass -- reads on five and more copies of a locus -- are matched once more by the same lane-per-read code with room for
+// NPEND2 parked locations and MQR2 queue slots per strand (registers and LDS of an instance that only sees a few per cent
+// of the reads).  What outgrows that too, long equal ranges and long reads go to the wave-per-read kernel.
+#define NPEND2 12
+#define MQR2 16u
+__host__ __device__ constexpr uint32_t stg_bytes2() { return MQR2 * 64u * 5u + 64u * 128u + 256u; }
 #define STG_PAD 16u
 #ifndef RH_KEEP_TW_MAXW
 #define RH_KEEP_TW_MAXW 4
 #endif
 #define NPEND 4      // verified locations a lane parks until their scores are computed (flush_pending), each with the
                      // set of lists through which it was reached (= its update() events)
-#define SLOT_NONE 7u
+#define SLOT_NONE 15u
+#define SLOT_BIG 14u   // cslot of a read that is handed over because of a long equal range (not for want of room: the second pass would be no help)
 #define PEND_OVF 0xffu // p_n of a read that is handed over to the wave-cooperative matcher (match_wave.hip)
 #define BIG_T 48u      // an equal range / bucket scan longer than this many entries is not walked by one lane: hand-over
 
-template <int W, bool SCORES, bool ALL>
+// bits 9..14 of a parked location's meta word: the lists whose update() call it has had
+#define PM_LM_SHIFT 9
+#define PM_LM_MASK (63u << PM_LM_SHIFT)
+template <int W, bool SCORES, bool ALL, int NP = NPEND>
 struct LaneState {
     // read
     uint64_t O[W];      // oriented read, 32 bases per word
@@ -99,11 +110,10 @@ struct LaneState {
     uint32_t crpos, ckk; // last seed window looked at and its per-segment mismatch counts (4 x 8 bits)
     // SCORES: verified locations whose score is still to be computed, and the update() events that refer
     // to them, in event order (see flush_pending)
-    uint32_t p_pos[NPEND], p_meta[NPEND]; // text position; k | strand << 8 | fragment << 16
+    uint32_t p_pos[NP], p_meta[NP]; // text position; k | strand << 8 | lists << 9 | fragment << 16
     uint64_t p_tw[W <= RH_KEEP_TW_MAXW ? W : 1]; // aligned text words of pending location 0 (kept for reads of up to 128 bases;
                                           // longer ones read the text again when they score: the registers are worth more)
     uint32_t p_n, cslot;                  // locations, slot of the memo
-    uint32_t p_lm;                        // 6 bits per location: the lists whose update() call it has had (bit 6 j + la)
     uint32_t nhit; // matchAll: hits appended for this read
     // work counters of this read, packed (a register each would cost six of the 168): cA = L:4 | V:12 | S:12, cB = P:11 | C:11 | H:10.
     // No field overflows without the read being handed over -- a lane walks at most BIG_T entries of each of its 12 equal
@@ -121,13 +131,40 @@ struct LaneState {
 };
 
 
+// element j of a small register array, j a run-time value (selects over static indices: a run-time index would send the
+// array through scratch memory)
+template <int N>
+__device__ __forceinline__ uint32_t sel(const uint32_t (&v)[N], uint32_t j)
+{
+    // (an OR of masked words, not a chain of selects: the optimiser turns such a chain over the elements of one array into a
+    // load at a run-time index, and the array -- with it the whole lane state -- then lives in scratch memory)
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r |= j == (uint32_t)i ? v[i] : 0u;
+    return r;
+}
+template <int N>
+__device__ __forceinline__ float sel(const float (&v)[N], uint32_t j)
+{
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r |= j == (uint32_t)i ? __float_as_uint(v[i]) : 0u;
+    return __uint_as_float(r);
+}
+template <int N, class T>
+__device__ __forceinline__ void put(T (&v)[N], uint32_t j, T x)
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = j == (uint32_t)i ? x : v[i];
+}
+
 // the update() call itself: the best/unique fold, or the matchAll append
-template <int W, bool SCORES, bool ALL>
-__device__ __forceinline__ void deliver(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, uint32_t pos, uint32_t meta, float score)
+template <int W, bool SCORES, bool ALL, int NP>
+__device__ __forceinline__ void deliver(const MatchArgs &a, LaneState<W, SCORES, ALL, NP> &s, uint32_t pos, uint32_t meta, float score)
 {
     if (ALL) {
         unsigned long long slot = wave_append_slot(a.raw_count);
-        if (slot < a.raw_cap) a.raw[slot] = make_uint4((uint32_t)s.r, pos, __float_as_uint(score), meta);
+        if (slot < a.raw_cap) a.raw[slot] = make_uint4((uint32_t)s.r, pos, __float_as_uint(score), meta & ~PM_LM_MASK);
         s.nhit++;
     } else {
         fold_update<SCORES>((meta >> 8) & 1, a.t.fileid, pos, meta & 0xff, score, s.eps(a.filter_mult), meta >> 16, s.info, s.iscore);
@@ -148,15 +185,17 @@ __device__ __forceinline__ void deliver(const MatchArgs &a, LaneState<W, SCORES,
 // a later list, after other windows, has its later events at their own lists' turns -- not at its first one's).
 // Two consecutive update() calls for the same location are one: the second finds the record either at that location
 // (nothing differs), NonUnique with the same score comparison that just failed, or as untouched as the first left it.
-template <int W, bool SCORES, bool ALL, class Row>
-__device__ __forceinline__ void flush_pending(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL, const Row &qrow)
+template <int W, bool SCORES, bool ALL, class Row, int NP>
+__device__ __forceinline__ void flush_pending(const MatchArgs &a, LaneState<W, SCORES, ALL, NP> &s, const double *sLL, const Row &qrow)
 {
-    float sc0 = 1.0f, sc1 = 1.0f, sc2 = 1.0f, sc3 = 1.0f; // (scalars and selects: a run-time index would send them through scratch memory)
+    float sc[NP]; // (static indices only: sel / put)
+#pragma unroll
+    for (int i = 0; i < NP; ++i) sc[i] = 1.0f;
 #pragma unroll 1
     for (uint32_t j = 0; j < s.p_n; ++j) {
         if (!SCORES || (RH_ABLATE & 1)) break; // ComputeScore<...,false>: 1.0f (ComputeScore.hpp:31-45)
-        const uint32_t pos = j == 0 ? s.p_pos[0] : j == 1 ? s.p_pos[1] : j == 2 ? s.p_pos[2] : s.p_pos[3];
-        const uint32_t meta = j == 0 ? s.p_meta[0] : j == 1 ? s.p_meta[1] : j == 2 ? s.p_meta[2] : s.p_meta[3];
+        const uint32_t pos = sel<NP>(s.p_pos, j);
+        const uint32_t meta = sel<NP>(s.p_meta, j);
         const uint32_t inv = (meta >> 8) & 1;
         uint64_t Ow[W], tw[W];
         if ((int)inv == s.inv) {
@@ -182,52 +221,74 @@ __device__ __forceinline__ void flush_pending(const MatchArgs &a, LaneState<W, S
             for (int i = 0; i < W; ++i) tw[i] = sh ? ((t[i] << sh) | (t[i + 1] >> (64 - sh))) : t[i];
         }
         const float v = score_location<W>(sLL, Ow, tw, s.patl, qrow, a.b.qual != nullptr, inv);
-        if (j == 0) sc0 = v; else if (j == 1) sc1 = v; else if (j == 2) sc2 = v; else sc3 = v;
+        put<NP>(sc, j, v);
     }
-    // the event sequence: 2 bits per event = its location
-    uint64_t ev = 0;
-    uint32_t nev = 0;
+    auto lm_of = [&](uint32_t meta) { return (meta >> PM_LM_SHIFT) & 63u; };
     if (s.p_n == 1) {
-        nev = (s.p_lm & 63u) ? 1u : 0u; // (all events of the read are this location's: one call)
-    } else if (ALL) {
+        if (lm_of(s.p_meta[0])) deliver<W, SCORES, ALL>(a, s, s.p_pos[0], s.p_meta[0], sc[0]); // (all events of the read are this location's: one call)
+        return;
+    }
+    if (ALL) {
         // matchAll keeps one hit per location (process_loaded); unifyMatches orders them afterwards (rh_all_finish)
-#pragma unroll
-        for (uint32_t j = 0; j < NPEND; ++j)
-            if (j < s.p_n && ((s.p_lm >> (6 * j)) & 63u)) { ev |= (uint64_t)j << (2 * nev); nev++; }
-    } else if (s.p_n >= 2) {
-        // rank of every location by (strand, position); ord = the locations in that order, 2 bits each
-        uint32_t ord = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < NPEND; ++j) {
-            const uint64_t kj = ((uint64_t)((s.p_meta[j] >> 8) & 1u) << 32) | s.p_pos[j];
-            uint32_t rank = 0;
-#pragma unroll
-            for (uint32_t i = 0; i < NPEND; ++i) {
-                const uint64_t ki = ((uint64_t)((s.p_meta[i] >> 8) & 1u) << 32) | s.p_pos[i];
-                if (i != j && i < s.p_n && (ki < kj || (ki == kj && i < j))) rank++;
-            }
-            if (j < s.p_n) ord |= j << (2 * rank);
+#pragma unroll 1
+        for (uint32_t j = 0; j < s.p_n; ++j) {
+            const uint32_t meta = sel<NP>(s.p_meta, j);
+            if (lm_of(meta)) deliver<W, SCORES, ALL>(a, s, sel<NP>(s.p_pos, j), meta, sel<NP>(sc, j));
         }
-        const uint32_t strands = ((s.p_meta[0] >> 8) & 1u) | (((s.p_meta[1] >> 8) & 1u) << 1) | (((s.p_meta[2] >> 8) & 1u) << 2) | (((s.p_meta[3] >> 8) & 1u) << 3);
-        uint32_t last = SLOT_NONE;
+        return;
+    }
+    if (s.p_n < 2) return;
+    // rank of every location by (strand, position); ord = the locations in that order, 4 bits each
+    uint64_t ord = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < (uint32_t)NP; ++j) {
+        const uint64_t kj = ((uint64_t)((s.p_meta[j] >> 8) & 1u) << 32) | s.p_pos[j];
+        uint32_t rank = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < (uint32_t)NP; ++i) {
+            const uint64_t ki = ((uint64_t)((s.p_meta[i] >> 8) & 1u) << 32) | s.p_pos[i];
+            if (i != j && i < s.p_n && (ki < kj || (ki == kj && i < j))) rank++;
+        }
+        if (j < s.p_n) ord |= (uint64_t)j << (4 * rank);
+    }
+    if (NP <= 4) {
+        // the event sequence first (2 bits per event = its location; at most 4 x 6 events), then the calls: the fold's code
+        // exists once and runs as often as the lane with the most events needs it
+        uint64_t ev = 0;
+        uint32_t nev = 0, last = SLOT_NONE;
 #pragma unroll 1
         for (uint32_t sl = 0; sl < 12; ++sl) { // strand, list
             const uint32_t inv = sl >= 6 ? 1u : 0u, la = sl - 6 * inv;
 #pragma unroll
-            for (uint32_t rk = 0; rk < NPEND; ++rk) {
-                const uint32_t j = (ord >> (2 * rk)) & 3u;
-                if (rk < s.p_n && ((strands >> j) & 1u) == inv && ((s.p_lm >> (6 * j + la)) & 1u) && j != last) {
+            for (uint32_t rk = 0; rk < (uint32_t)NP; ++rk) {
+                const uint32_t j = (uint32_t)(ord >> (4 * rk)) & 15u;
+                const uint32_t meta = sel<NP>(s.p_meta, j);
+                if (rk < s.p_n && ((meta >> 8) & 1u) == inv && ((meta >> (PM_LM_SHIFT + la)) & 1u) && j != last) {
                     ev |= (uint64_t)j << (2 * nev); nev++; last = j;
                 }
             }
         }
-    }
 #pragma unroll 1
-    for (uint32_t e = 0; e < nev; ++e) {
-        const uint32_t j = (uint32_t)(ev >> (2 * e)) & 3u;
-        deliver<W, SCORES, ALL>(a, s, j == 0 ? s.p_pos[0] : j == 1 ? s.p_pos[1] : j == 2 ? s.p_pos[2] : s.p_pos[3],
-                                j == 0 ? s.p_meta[0] : j == 1 ? s.p_meta[1] : j == 2 ? s.p_meta[2] : s.p_meta[3],
-                                j == 0 ? sc0 : j == 1 ? sc1 : j == 2 ? sc2 : sc3);
+        for (uint32_t e = 0; e < nev; ++e) {
+            const uint32_t j = (uint32_t)(ev >> (2 * e)) & 3u;
+            deliver<W, SCORES, ALL>(a, s, sel<NP>(s.p_pos, j), sel<NP>(s.p_meta, j), sel<NP>(sc, j));
+        }
+    } else {
+        // (the second pass over the reads with many locations: the calls where they are found)
+        uint32_t last = SLOT_NONE;
+#pragma unroll 1
+        for (uint32_t sl = 0; sl < 12; ++sl) {
+            const uint32_t inv = sl >= 6 ? 1u : 0u, la = sl - 6 * inv;
+#pragma unroll 1
+            for (uint32_t rk = 0; rk < s.p_n; ++rk) {
+                const uint32_t j = (uint32_t)(ord >> (4 * rk)) & 15u;
+                const uint32_t meta = sel<NP>(s.p_meta, j);
+                if (((meta >> 8) & 1u) == inv && ((meta >> (PM_LM_SHIFT + la)) & 1u) && j != last) {
+                    deliver<W, SCORES, ALL>(a, s, sel<NP>(s.p_pos, j), meta, sel<NP>(sc, j));
+                    last = j;
+                }
+            }
+        }
     }
 }
 
@@ -265,8 +326,8 @@ struct CandText {
     uint64_t t2;
     uint64_t t[W + 2];
 };
-template <int W, bool SCORES, bool ALL>
-__device__ __forceinline__ void cand_load(const MatchArgs &a, const LaneState<W, SCORES, ALL> &s, uint32_t rpos, CandText<W> &c)
+template <int W, bool SCORES, bool ALL, int NP>
+__device__ __forceinline__ void cand_load(const MatchArgs &a, const LaneState<W, SCORES, ALL, NP> &s, uint32_t rpos, CandText<W> &c)
 {
     const uint64_t *__restrict__ T = a.t.text;
     const uint64_t wi0 = rpos >> 5;
@@ -284,8 +345,8 @@ __device__ __forceinline__ void cand_load(const MatchArgs &a, const LaneState<W,
 
 // lmask = the lists (bit la) through which this window was reached one right after the other: the window is looked at
 // once, its update() events are delivered list by list
-template <int W, bool SCORES, bool ALL, bool DEFER>
-__device__ __forceinline__ void process_loaded(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL,
+template <int W, bool SCORES, bool ALL, bool DEFER, int NP>
+__device__ __forceinline__ void process_loaded(const MatchArgs &a, LaneState<W, SCORES, ALL, NP> &s, const double *sLL,
                                                uint32_t rpos, uint32_t lmask, const CandText<W> &c)
 {
     if (s.p_n == PEND_OVF) return; // handed over
@@ -323,11 +384,11 @@ __device__ __forceinline__ void process_loaded(const MatchArgs &a, LaneState<W, 
     uint32_t parked = SLOT_NONE; // ... or one that is parked already (reached again after other windows: a repeat)
     if (DEFER && pos != s.cpos) {
 #pragma unroll
-        for (uint32_t j = 0; j < NPEND; ++j)
+        for (uint32_t j = 0; j < (uint32_t)NP; ++j)
             if (j < s.p_n && s.p_pos[j] == pos && ((s.p_meta[j] >> 8) & 1u) == (uint32_t)s.inv) parked = j;
     }
     if (parked != SLOT_NONE) {
-        const uint32_t meta0 = parked == 0 ? s.p_meta[0] : parked == 1 ? s.p_meta[1] : parked == 2 ? s.p_meta[2] : s.p_meta[3];
+        const uint32_t meta0 = sel<NP>(s.p_meta, parked);
         s.cpos = pos; s.cok = true; s.ck = meta0 & 0xffu; s.cscore = 1.0f; s.cfrag = meta0 >> 16; s.cslot = parked;
     } else if (pos != s.cpos) {
         s.cpos = pos;
@@ -357,17 +418,13 @@ __device__ __forceinline__ void process_loaded(const MatchArgs &a, LaneState<W, 
         const float sc = 1.0f; // ComputeScore<...,false>, ComputeScore.hpp:31-45 (scores on: computed by flush_pending)
         s.cok = true; s.ck = total; s.cscore = sc; s.cfrag = frag; s.cslot = SLOT_NONE;
         if (DEFER) { // the score is computed later (flush_pending): park the location
-            if (s.p_n == NPEND) { s.p_n = PEND_OVF; return; } // out of room => the read is handed over
+            if (s.p_n == (uint32_t)NP) { s.p_n = PEND_OVF; return; } // out of room => the read is handed over
             const uint32_t meta0 = total | ((uint32_t)s.inv << 8) | (frag << 16);
-            if (s.p_n == 1) { s.p_pos[1] = pos; s.p_meta[1] = meta0; }
-            else if (s.p_n == 2) { s.p_pos[2] = pos; s.p_meta[2] = meta0; }
-            else if (s.p_n == 3) { s.p_pos[3] = pos; s.p_meta[3] = meta0; }
-            else {
-                s.p_pos[0] = pos; s.p_meta[0] = meta0;
-                if (SCORES && W <= RH_KEEP_TW_MAXW) {
+            put<NP>(s.p_pos, s.p_n, pos);
+            put<NP>(s.p_meta, s.p_n, meta0);
+            if (s.p_n == 0 && SCORES && W <= RH_KEEP_TW_MAXW) {
 #pragma unroll
-                    for (int j = 0; j < W; ++j) s.p_tw[W <= RH_KEEP_TW_MAXW ? j : 0] = tw[j];
-                }
+                for (int j = 0; j < W; ++j) s.p_tw[W <= RH_KEEP_TW_MAXW ? j : 0] = tw[j];
             }
             s.cslot = s.p_n++;
             reg = true;
@@ -386,16 +443,20 @@ __device__ __forceinline__ void process_loaded(const MatchArgs &a, LaneState<W, 
     }
     const uint32_t meta = s.ck | ((uint32_t)s.inv << 8) | (s.cfrag << 16);
     const uint32_t ne = __popc(events);
+    (void)meta; (void)ne;
     if (!DEFER) {
         for (uint32_t e = 0; e < ne; ++e) deliver<W, SCORES, ALL>(a, s, s.cpos, meta, s.cscore);
         return;
     }
     // park the events: the lists of this location's update() calls (flush_pending puts them in order)
-    s.p_lm |= events << (6 * s.cslot);
+    // (every word is written, with static indices: a conditional store would be turned into one store at a run-time index,
+    // and the parked locations -- with them the whole lane state -- would live in scratch memory)
+#pragma unroll
+    for (uint32_t j = 0; j < (uint32_t)NP; ++j) s.p_meta[j] |= (s.cslot == j ? events : 0u) << PM_LM_SHIFT;
 }
 
-template <int W, bool SCORES, bool ALL, bool DEFER>
-__device__ __forceinline__ void process_candidate(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL,
+template <int W, bool SCORES, bool ALL, bool DEFER, int NP>
+__device__ __forceinline__ void process_candidate(const MatchArgs &a, LaneState<W, SCORES, ALL, NP> &s, const double *sLL,
                                                   uint32_t rpos, uint32_t lmask)
 {
     if (s.p_n == PEND_OVF) return; // handed over
@@ -409,8 +470,8 @@ __device__ __forceinline__ void process_candidate(const MatchArgs &a, LaneState<
 // candidate order.  All bucket-table loads are issued together, then the first two entries of every bucket
 // together.  A scan longer than BIG_T entries, or more survivors than the queue holds (repeat-rich loci only),
 // hands the read over to the wave-cooperative matcher: no lane walks a long range alone.
-template <int W, bool SCORES, bool ALL, int LA0, int LA1>
-__device__ __forceinline__ void scan_lists(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, uint32_t *q_pos, uint8_t *q_la, uint32_t &qn)
+template <int W, bool SCORES, bool ALL, int LA0, int LA1, int NP>
+__device__ __forceinline__ void scan_lists(const MatchArgs &a, LaneState<W, SCORES, ALL, NP> &s, uint32_t *q_pos, uint8_t *q_la, uint32_t &qn)
 {
     const uint32_t bb = a.b_bits;
     const uint64_t mb = (bb >= 64) ? ~0ull : ((1ull << bb) - 1);
@@ -503,8 +564,8 @@ __device__ __forceinline__ void scan_lists(const MatchArgs &a, LaneState<W, SCOR
 // without reading them.  The lane enumerates the equal ranges of all lists in list order -- the canonical
 // candidate order -- eight entries per round trip, applies the partner filter and queues the survivors; a
 // full queue is drained and refilled (the only state across a drain is the enumeration offset).
-template <int W, bool SCORES, bool ALL, bool DEFER, int LA0, int LA1>
-__device__ __forceinline__ void match_lists_fine(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL,
+template <int W, bool SCORES, bool ALL, bool DEFER, int LA0, int LA1, int NP>
+__device__ __forceinline__ void match_lists_fine(const MatchArgs &a, LaneState<W, SCORES, ALL, NP> &s, const double *sLL,
                                                  uint32_t *q_pos, uint8_t *q_la)
 {
     const uint32_t bb = a.b_bits;
@@ -647,8 +708,8 @@ __device__ __forceinline__ void match_lists_fine(const MatchArgs &a, LaneState<W
 }
 
 // lists [LA0, LA1) of one strand
-template <int W, bool SCORES, bool ALL, bool FINE, bool DEFER, int LA0, int LA1>
-__device__ __forceinline__ void match_lists(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL,
+template <int W, bool SCORES, bool ALL, bool FINE, bool DEFER, int LA0, int LA1, int NP>
+__device__ __forceinline__ void match_lists(const MatchArgs &a, LaneState<W, SCORES, ALL, NP> &s, const double *sLL,
                                             uint32_t *q_pos, uint8_t *q_la)
 {
     if (FINE) { match_lists_fine<W, SCORES, ALL, DEFER, LA0, LA1>(a, s, sLL, q_pos, q_la); return; }
@@ -725,17 +786,20 @@ __device__ __forceinline__ void quals_landed()
 // qlast (the last call of a read, scores on): while the queues are drained for the last time, the qualities of the wave's
 // reads travel into the wave's region if quals_ahead() says so (at quals_at() when the function returns and
 // quals_landed() has waited).
-template <int W, bool SCORES, bool ALL, bool DEFER, bool WIDE, int LA0, int LA1>
-__device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL, uint8_t *stg, bool act,
+template <int W, bool SCORES, bool ALL, bool DEFER, bool WIDE, int LA0, int LA1, int NP>
+__device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W, SCORES, ALL, NP> &s, const double *sLL, uint8_t *stg, bool act,
                                                  bool qlast = false)
 {
+    // (queue slots per lane and strand, and where the rows lie behind the queue: the first pass' or the second's)
+    constexpr uint32_t MQRn = NP == NPEND ? MQR : MQR2, ROWBUF_OFFn = MQRn * 64u * 5u, BKX_OFFn = ROWBUF_OFFn + 64u * 128u;
+    constexpr bool has_pass2_rows = SCORES || ALL; // (bucket rows with parked hits: a second pass stands behind the first)
     constexpr int NL = LA1 - LA0;
     uint32_t lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane)); // (not to be carried across the tile loop of the kernel)
     // the wave's LDS region in this mode: MQR x 64 queued positions, MQR x 64 lists, 64 rows of 128 bytes
     uint32_t *q_pos = reinterpret_cast<uint32_t *>(stg) + lane;
-    uint8_t *q_la = stg + MQR * 64 * 4 + lane;
-    uint8_t *rowbuf = stg + ROWBUF_OFF;
+    uint8_t *q_la = stg + MQRn * 64 * 4 + lane;
+    uint8_t *rowbuf = stg + ROWBUF_OFFn;
     const uint32_t bb = a.b_bits;
     const uint32_t gbits = a.ix.fbits, pbits = a.ix.pbits, p16 = pbits < 16 ? pbits : 16;
     const uint32_t pmask = (1u << pbits) - 1;
@@ -774,7 +838,7 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
     auto bucket_of = [&](int la) { return wide ? (uint32_t)(msig_wide(la) >> a.ix.pshift) : (msig_of(la) >> gbits); };
     uint32_t qn = 0, q_last = 0, q_lastla = 0; // queue fill; position and list bits of the entry pushed last
     uint4 va0, va1, va2, va3, va4, va5, va6, va7; // (eight scalars, not an array: the array went through scratch memory)
-    uint32_t *bkx = reinterpret_cast<uint32_t *>(stg + BKX_OFF);
+    uint32_t *bkx = reinterpret_cast<uint32_t *>(stg + BKX_OFFn);
     // the eight loads of list la: lane (8g+j) reads piece j of the row of owner 8*it+g.  The owners' bucket numbers go
     // through LDS transposed, so that a loader finds its eight at bkx[8g .. 8g+7] (an owner that takes no part: row 0)
     // (a macro, not a lambda taking the array by reference: that sent the eight rows through scratch memory)
@@ -904,7 +968,7 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
             }
             if (!wide) s.addC(e_cnt); // (wide: counted when the text confirms the membership)
             s.addP(e_cnt);
-            if (e_cnt > BIG_T) { s.p_n = PEND_OVF; e_cnt = 0; } // a long equal range is walked by a whole wave (match_wave.hip)
+            if (e_cnt > BIG_T) { s.p_n = PEND_OVF; s.cslot = SLOT_BIG; e_cnt = 0; } // a long equal range is walked by a whole wave (match_wave.hip)
             if (RH_ABLATE & 4) e_cnt = 0;
         }
         const uint32_t rk = wide ? rh_fp16(r) : (r >> (pbits - p16)); // what the 16 key bits of a row entry are compared with
@@ -914,39 +978,74 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
         // more than MQR queue slots for one strand (repeat-rich loci only) hands its read over: the queues are drained
         // once, behind the lists, where the registers that hold the rows in flight are free again.
         // A lane whose row is complex finds its entries in the overflow array: their first two are requested here and looked
-        // at behind the loop of the lanes with simple rows -- the round trip is hidden behind that loop instead of standing in
+        // at behind the lanes with simple rows -- the round trip is hidden behind their work instead of standing in
         // front of every step of the whole wave (with a skewed base composition nearly every wave has such a lane in every
         // list).  A lane is of one kind for the whole list, so the order of its own entries is what it was.
         U64x2 pre = {0ull, 0ull};
         if (e_ovf && e_cnt) pre = load2(reinterpret_cast<const uint64_t *>(a.ix.ent[la] + e_base)); // (two entries; the array is padded by one)
-        auto take = [&](bool step, uint32_t pos, uint32_t x) {
-            // seed popcount filter (match.hpp:386) on the partner symbols the entry carries: more than seedkmax
-            // known mismatches => rejected without touching the text (exact: the full count can only be larger)
-            bool pass = step && (wide ? (x == 0u) : (__popc(((x >> 1) | x) & 0x55555555u) <= a.seedkmax));
+        // a survivor of the partner filter goes to the lane's queue; a window that is in the queue already only gets this
+        // list's bit set (the lane's last queue entry is kept in registers: for it nothing is read back).  A lane that needs
+        // more than MQRn queue slots for one strand (repeat-rich loci only) hands its read over: the queues are drained
+        // once, behind the lists, where the registers that hold the rows in flight are free again.
+        auto take = [&](bool pass, uint32_t pos) {
             const bool merge = pass && qn && pos == q_last;
             if ((!wide || DEFER) && pass && !merge && qn >= 2) { // (repeats: a window that stands further up in the queue gets this list's bit there; see queue_push)
                 for (uint32_t k = 0; k + 1 < qn; ++k)
                     if (q_pos[k * 64] == pos) { q_la[k * 64] |= (uint8_t)(1u << la); pass = false; break; }
             }
-            if (pass && !merge && qn == MQR) { s.p_n = PEND_OVF; e_cnt = 0; pass = false; } // (match_wave.hip takes the read)
+            if (pass && !merge && qn == MQRn) { s.p_n = PEND_OVF; e_cnt = 0; pass = false; } // (the read is handed over)
             const uint32_t slot = merge ? qn - 1 : qn;
             const uint32_t lav = (merge ? q_lastla : 0u) | (1u << la);
             if (pass) { q_pos[slot * 64] = pos; q_la[slot * 64] = (uint8_t)lav; q_last = pos; q_lastla = lav; qn = slot + 1; }
-            e_j += step ? 1u : 0u;
         };
-        while (__any(!e_ovf && e_j < e_cnt)) { // simple rows: 6 bytes at halfword 4 + 3 * (e_base + e_j) of the row
-            const bool step = !e_ovf && e_j < e_cnt;
-            const uint32_t h = step ? 4 + 3 * (e_base + e_j) : 4u;
-            const uint32_t d0 = row(h >> 1), d1 = row((h >> 1) + 1);
-            const uint32_t key = (h & 1) ? (d0 >> 16) : (d0 & 0xffffu);
-            take(step, (h & 1) ? d1 : ((d0 >> 16) | (d1 << 16)), key ^ rk);
+        // seed popcount filter (match.hpp:386) on the partner symbols the entry carries: more than seedkmax
+        // known mismatches => rejected without touching the text (exact: the full count can only be larger)
+        auto passes = [&](uint32_t x) { return wide ? (x == 0u) : (__popc(((x >> 1) | x) & 0x55555555u) <= a.seedkmax); };
+        // Simple rows.  Nearly every entry that is no copy of the read's locus fails the filter (8 partner symbols, at most
+        // seedkmax mismatches: 0.4 % of the chance entries pass), so the entries are filtered first -- four keys of the lane's
+        // group per step, their LDS reads in flight together, nothing but a bit per entry kept -- and only the survivors,
+        // one or two per lane, take the path through the queue.  (The steps of the wave are those of its lane with the most
+        // entries: a quarter of them this way, which is what a skewed base composition, with its long groups, needs.)
+        uint32_t passm = 0; // bit j: entry j of the lane's group survives (a group of a simple row has at most 15 entries)
+        while (__any(!e_ovf && e_j < e_cnt)) {
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {
+                const uint32_t jj = e_j + u;
+                const bool ok = !e_ovf && jj < e_cnt;
+                const uint32_t h = ok ? 4 + 3 * (e_base + jj) : 4u; // the key: halfword 4 + 3 * entry of the row
+                const uint32_t d0 = row(h >> 1);
+                const uint32_t key = (h & 1) ? (d0 >> 16) : (d0 & 0xffffu);
+                passm |= (ok && passes(key ^ rk) ? 1u : 0u) << (jj & 31u);
+            }
+            e_j += 4;
         }
-        while (__any(e_ovf && e_j < e_cnt)) { // complex rows: {key, pos} in the overflow array
-            const bool step = e_ovf && e_j < e_cnt;
-            uint2 e = make_uint2((uint32_t)pre.a, (uint32_t)(pre.a >> 32));
-            if (e_j == 1) e = make_uint2((uint32_t)pre.b, (uint32_t)(pre.b >> 32));
-            if (step && e_j >= 2) e = a.ix.ent[la][e_base + e_j];
-            take(step, e.y, wide ? (e.x ^ r) : ((e.x & pmask) ^ r));
+        // more survivors in one list than a lane of the first pass parks locations: a read on that many copies of its
+        // locus.  It is handed on here, before anything of it is verified for nothing (handing over is always allowed: who
+        // takes the read does all of it).
+        if (NP == NPEND && has_pass2_rows && DEFER && __popc(passm) > NPEND) { s.p_n = PEND_OVF; passm = 0; e_cnt = 0; }
+        while (__any(passm != 0)) {
+            const bool step = passm != 0;
+            const uint32_t jj = step ? (uint32_t)__ffs((int)passm) - 1u : 0u;
+            passm &= passm - 1u;
+            const uint32_t h = step ? 4 + 3 * (e_base + jj) : 4u; // the position: the two halfwords behind the key
+            const uint32_t d0 = row(h >> 1), d1 = row((h >> 1) + 1);
+            take(step, (h & 1) ? d1 : ((d0 >> 16) | (d1 << 16)));
+        }
+        // complex rows: {key, pos} in the overflow array.  The first two entries are there (requested above); the rest comes
+        // four at a time, their loads in flight together -- one round trip per four entries, not one per entry
+        auto take_ovf = [&](bool ok, uint2 e) { take(ok && passes(wide ? (e.x ^ r) : ((e.x & pmask) ^ r)), e.y); };
+        if (__any(e_ovf && e_cnt)) {
+            take_ovf(e_ovf && e_cnt > 0, make_uint2((uint32_t)pre.a, (uint32_t)(pre.a >> 32)));
+            take_ovf(e_ovf && e_cnt > 1, make_uint2((uint32_t)pre.b, (uint32_t)(pre.b >> 32)));
+        }
+        e_j = 2;
+        while (__any(e_ovf && e_j < e_cnt)) {
+            uint2 e[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) e[u] = (e_ovf && e_j + u < e_cnt) ? a.ix.ent[la][e_base + e_j + u] : make_uint2(0u, 0u);
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) take_ovf(e_ovf && e_j + u < e_cnt, e[u]);
+            e_j += 4;
         }
 #if RH_PHASE_TIMING
         s.tD += PH_NOW() - ph1;
@@ -980,13 +1079,13 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
 }
 
 // both strands of one read with bucket rows: every lane of the wave comes along, `act` tells which ones have a read
-template <int W, bool SCORES, bool ALL, bool DEFER, bool WIDE>
-__device__ __forceinline__ void match_read_rows(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL, uint8_t *stg, bool act)
+template <int W, bool SCORES, bool ALL, bool DEFER, bool WIDE, int NP>
+__device__ __forceinline__ void match_read_rows(const MatchArgs &a, LaneState<W, SCORES, ALL, NP> &s, const double *sLL, uint8_t *stg, bool act, bool quals_dma)
 {
     const uint32_t patl = act ? s.patl : 32u * W;
-    s.p_n = s.p_lm = 0; s.cslot = SLOT_NONE;
+    s.p_n = 0; s.cslot = SLOT_NONE;
 #pragma unroll
-    for (int j = 0; j < NPEND; ++j) { s.p_pos[j] = 0; s.p_meta[j] = 0; }
+    for (int j = 0; j < NP; ++j) { s.p_pos[j] = 0; s.p_meta[j] = 0; }
     uint64_t rhi = 0, rlo = 0;
     if (act) seed_halves<W>(s.O, a.l, s.shi, s.slo, rhi, rlo);
     else { s.shi = s.slo = 0; }
@@ -1009,21 +1108,21 @@ __device__ __forceinline__ void match_read_rows(const MatchArgs &a, LaneState<W,
             const unsigned st = (unsigned)(s.info >> ST_SHIFT), er = (unsigned)(s.info >> ER_SHIFT) & 15;
             match_lists_rows<W, SCORES, ALL, DEFER, WIDE, 1, 6>(a, s, sLL, stg, go && !(st == (unsigned)(inv ? ST_REVERSE : ST_STRAIGHT) && er == 0));
         } else {
-            match_lists_rows<W, SCORES, ALL, DEFER, WIDE, 0, 6>(a, s, sLL, stg, go, inv != 0);
+            match_lists_rows<W, SCORES, ALL, DEFER, WIDE, 0, 6>(a, s, sLL, stg, go, quals_dma && inv != 0);
         }
     }
 }
 
 // both strands of one read (UniqueMatcher::match / AllMatcher::match, matchUniqueImplementation.cpp:396-500,
 // matchAllImplementation.cpp:261-355): s.O holds the read as given on entry, its reverse complement on exit
-template <int W, bool SCORES, bool ALL, bool FINE, bool DEFER>
-__device__ __forceinline__ void match_read(const MatchArgs &a, LaneState<W, SCORES, ALL> &s, const double *sLL, uint32_t *q_pos,
+template <int W, bool SCORES, bool ALL, bool FINE, bool DEFER, int NP>
+__device__ __forceinline__ void match_read(const MatchArgs &a, LaneState<W, SCORES, ALL, NP> &s, const double *sLL, uint32_t *q_pos,
                                            uint8_t *q_la)
 {
     const uint32_t patl = s.patl;
-    s.p_n = s.p_lm = 0; s.cslot = SLOT_NONE;
+    s.p_n = 0; s.cslot = SLOT_NONE;
 #pragma unroll
-    for (int j = 0; j < NPEND; ++j) { s.p_pos[j] = 0; s.p_meta[j] = 0; }
+    for (int j = 0; j < NP; ++j) { s.p_pos[j] = 0; s.p_meta[j] = 0; }
     uint64_t rhi, rlo;
     seed_halves<W>(s.O, a.l, s.shi, s.slo, rhi, rlo);
     for (int inv = 0; inv < 2; ++inv) {
@@ -1054,18 +1153,26 @@ __device__ __forceinline__ void match_read(const MatchArgs &a, LaneState<W, SCOR
 // The matcher proper: lane i of the grid takes read i of the batch.  A wave reads the bases of its 64 reads -- one
 // contiguous byte range of the caller's array -- through LDS, every lane packs its own read into registers, matches
 // both strands, and parks its hits (DEFER: scores on, or matchAll); then the wave reads the qualities of its reads the
-// same way and the lanes score and deliver together.  A read that needs more than NPEND locations,
-// or meets an equal range of more than BIG_T entries, is left untouched and its index appended to a.ovf_list: the
-// wave-cooperative matcher (match_wave.hip) does it all and counts it.
+// same way and the lanes score and deliver together.  A read that needs more than NPEND locations or more queue slots
+// than a lane has is left untouched and its index appended to a.ovf_list: the second pass (PASS2: this kernel again, over
+// that list, with NPEND2 locations and MQR2 queue slots per lane; its reads are scattered, so every lane fetches the bytes
+// of its own read) does it all and counts it.  What outgrows that as well, a read that meets an equal range of more than
+// BIG_T entries, and a read longer than a lane's registers go to a.ovf2_list: the wave-per-read matcher (match_wave.hip).
 // TK = kind of the bucket tables: 0 bucket starts, 1 directory entries (digests / fingerprints), 3 bucket rows,
 // 4 bucket rows of signatures wider than 32 bits
-template <int W, bool SCORES, bool ALL, int TK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 : 2))) void match_kernel(MatchArgs a_)
+template <int TK, bool SCORES, bool ALL>
+__host__ __device__ constexpr bool has_pass2() { return TK >= 3 && (SCORES || ALL); }
+
+template <int W, bool SCORES, bool ALL, int TK, bool PASS2>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PASS2 ? 2 : (W <= 5 ? 3 : 2)))) void match_kernel(MatchArgs a_)
 {
     constexpr bool FINE = TK != 0;
     constexpr bool DEFER = SCORES || ALL;
+    constexpr int NP = PASS2 ? NPEND2 : NPEND;
+    constexpr uint32_t STG = PASS2 ? stg_bytes2() : stg_bytes(W, TK);
+    static_assert(!PASS2 || has_pass2<TK, SCORES, ALL>(), "the second pass exists for bucket rows with parked hits only");
     __shared__ double sLL[SCORES ? RH_LL_SLOTS : 1];
-    __shared__ __attribute__((aligned(16))) uint8_t smem[4 * stg_bytes(W, TK)];
+    __shared__ __attribute__((aligned(16))) uint8_t smem[4 * STG];
     if (SCORES) { // the score table, once per workgroup
         for (int i = threadIdx.x; i < 1024; i += 256) sLL[i] = a_.LL[i];
         if (threadIdx.x == 0) sLL[RH_LL_ZERO] = 0.0;
@@ -1077,13 +1184,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
     // wave slots of a workgroup stay empty until its slowest wave has finished and the next workgroup has been
     // dispatched (16 % of the slot time on the C2 workload); with a fixed share of tiles per wave the grid waits for the
     // slowest wave at the end (11 %).
-    const uint64_t n_tiles = (a_.b.n_reads + 63) / 64;
+    const uint64_t n_items = PASS2 ? (uint64_t)*a_.ovf_count : a_.b.n_reads; // (second pass: the reads the first one listed)
+    const uint64_t n_tiles = (n_items + 63) / 64;
+    uint32_t *const tile_ctr = PASS2 ? a_.tile_ctr2 : a_.tile_ctr;
     uint32_t next_raw = 0; // (lane 0 holds the answer of the counter)
-    if ((threadIdx.x & 63) == 0) next_raw = atomicAdd(a_.tile_ctr, 1u);
+    if ((threadIdx.x & 63) == 0) next_raw = atomicAdd(tile_ctr, 1u);
     while (true) {
     const uint64_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)next_raw);
     if (tile >= n_tiles) break;
-    if ((threadIdx.x & 63) == 0) next_raw = atomicAdd(a_.tile_ctr, 1u);
+    if ((threadIdx.x & 63) == 0) next_raw = atomicAdd(tile_ctr, 1u);
     // (what depends on the lane number only is derived again for every tile: carried across the loop it would take
     // registers of all the rest)
     uint32_t tid = threadIdx.x;
@@ -1095,11 +1204,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
     asm volatile("" : "+s"(pa));
     const MatchArgs &a = *(const MatchArgs *)pa;
     const uint32_t lane = tid & 63;
-    uint8_t *stg = smem + (tid >> 6) * stg_bytes(W, TK);
+    uint8_t *stg = smem + (tid >> 6) * STG;
     uint32_t *q_pos = reinterpret_cast<uint32_t *>(stg) + lane;
     uint8_t *q_la = stg + MQ * 64 * 4 + lane;
     const unsigned ph_start = PH_NOW();
-    LaneState<W, SCORES, ALL> s;
+    LaneState<W, SCORES, ALL, NP> s;
     s.cA = s.cB = 0;
 #if RH_PHASE_TIMING
     s.tW = s.tD = s.tR = 0;
@@ -1109,7 +1218,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
     unsigned cR = 0;
     const uint64_t n = a.b.n_reads;
 
-    const uint64_t r = tile * 64 + lane;
+    const uint64_t item = tile * 64 + lane;
+    const bool have = item < n_items;
+    const uint64_t r = PASS2 ? (have ? (uint64_t)a.ovf_list[item] : n) : item;
     const uint64_t rc = r < n ? r : n; // lanes behind the batch: an empty range at its end
     const uint64_t o0 = a.b.off ? a.b.off[rc] : rc * (uint64_t)a.b.upatl;
     const uint64_t o1 = r < n ? (a.b.off ? a.b.off[r + 1] : o0 + a.b.upatl) : o0;
@@ -1118,13 +1229,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
     const uint32_t patl = span_bad ? 0u : (uint32_t)(o1 - o0);
     const uint32_t bsh = a.b.packed ? 2u : 0u; // packed bases: four per byte
     const uint32_t GL = a.b.gl; // reads the wave stages at a time: GL * max_patl fits its LDS region
-    const uint32_t stg_cap = stg_bytes(W, TK) - STG_PAD - 32u; // bytes of a group the region holds (skew, pad, over-read)
+    const uint32_t stg_cap = STG - STG_PAD - 32u; // bytes of a group the region holds (skew, pad, over-read)
+    bool elig = false, toolong = false, give = false;
+    if (PASS2) {
+        // ---- bases: every lane reads the bytes of its own read (the first pass found it eligible: it fits the registers and
+        // holds no symbol > 3 that a flag or the packing would have shown)
+        if (r < n) {
+            if (a.b.packed) {
+                pack_read_packed<W>(GlobalRow{a.b.bases + (o0 >> 2)}, patl, (uint32_t)o0 & 3u, s.O);
+                elig = true;
+            } else {
+                elig = pack_read<W>(GlobalRow{a.b.bases + o0}, patl, s.O);
+            }
+        }
+    } else {
     // ---- bases: global -> LDS -> registers
     // A read longer than the registers of this instance hold (32 W bases: longer than REAL_HIP_MAX_PATL, or than the
     // bound the caller declared), and every read of a group whose bytes do not fit the wave's LDS region because of such
     // a neighbour, is not staged at all: it is given to the wave-per-read matcher, which reads it from LDS words and
     // checks its eligibility itself.  Only offsets that run backwards or a read beyond REAL_HIP_MAX_PATL_LONG are errors.
-    bool elig = false, toolong = false, give = false;
     for (uint32_t g = 0; g < 64; g += GL) {
         const uint64_t gb = __shfl(o0, (int)g), ge = __shfl(o1, (int)(g + GL - 1));
         const bool fits = ge >= gb && ge - gb <= stg_cap;
@@ -1144,34 +1267,63 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
             }
         }
     }
+    }
     if (toolong) atomicOr(a.err_flags, 1u); // the host turns this into REAL_HIP_E_INVALID
     wave_lds_sync();
     // ---- match
     s.r = r; s.patl = patl; s.p_n = 0; s.nhit = 0;
-    if (elig && !ALL && !a.b.fresh) {
+    const bool fresh = !PASS2 && a.b.fresh; // (the first pass has started the records of the reads it hands on)
+    if (elig && !ALL && !fresh) {
         s.info = a.info[r];
         if (SCORES) s.iscore = a.score[r];
     }
-    if (!ALL && a.b.fresh) s.iscore = -3.402823466e+38f; // uniqueinfo(numpat): NoMatch (info 0), score -FLT_MAX (UniqueMatchInfo.hpp:191)
+    if (!ALL && fresh) s.iscore = -3.402823466e+38f; // uniqueinfo(numpat): NoMatch (info 0), score -FLT_MAX (UniqueMatchInfo.hpp:191)
     const unsigned ph_front = PH_NOW();
     s.o0 = o0; s.o1 = o1;
     if (TK >= 3) // bucket rows: lookups by lane groups, the whole wave comes along
-        match_read_rows<W, SCORES, ALL, DEFER, TK == 4>(a, s, sLL, stg, elig);
+        match_read_rows<W, SCORES, ALL, DEFER, TK == 4>(a, s, sLL, stg, elig, !PASS2);
     else if (elig)
         match_read<W, SCORES, ALL, FINE, DEFER>(a, s, sLL, q_pos, q_la);
     const bool ovf = give || (elig && s.p_n == PEND_OVF);
     if (ovf) {
-        // nothing of this read has been delivered: the wave-cooperative matcher does it all and counts it
-        const unsigned long long slot = wave_append_slot(a.ovf_count);
-        a.ovf_list[slot] = (uint32_t)r;
+        // nothing of this read has been delivered: whoever takes it does it all and counts it.  The first pass gives the
+        // reads that were too much for a lane to the second (where there is one); long equal ranges are not walked by lanes
+        // at all, and reads a lane cannot hold, or the second pass cannot either, are the wave-per-read matcher's.
+        const bool to_wave = PASS2 || !has_pass2<TK, SCORES, ALL>() || give || s.cslot == SLOT_BIG;
+        if (to_wave) {
+            const unsigned long long slot = wave_append_slot(a.ovf2_count);
+            a.ovf2_list[slot] = (uint32_t)r;
+        } else {
+            const unsigned long long slot = wave_append_slot(a.ovf_count);
+            a.ovf_list[slot] = (uint32_t)r;
+        }
         s.cA = s.cB = 0;
     }
     // ---- qualities: global -> LDS; score the parked hits and deliver them
     const uint8_t *qsrc_ = nullptr;
     uint32_t qbytes_ = 0, qlate_ = 0, qskew_ = 0;
-    const bool q_ahead = TK >= 3 && SCORES && quals_ahead(a, o0, o1, stg_cap, qsrc_, qbytes_, qlate_, qskew_); // (then match_lists_rows has started them)
+    const bool q_ahead = !PASS2 && TK >= 3 && SCORES && quals_ahead(a, o0, o1, stg_cap, qsrc_, qbytes_, qlate_, qskew_); // (then match_lists_rows has started them)
     if (q_ahead) quals_landed();
-    if (DEFER) {
+    if (DEFER && PASS2) {
+        // The reads of a tile are scattered: every lane copies the qualities of its own read into its 128-byte slot of the row
+        // buffer (free now), whole aligned dwords (what they hold besides the read's bytes lies in the same mapped words of
+        // the caller's array and is not looked at); a read that does not fit its slot is scored from global memory.
+        const bool want = elig && !ovf && s.p_n;
+        const bool in_lds = !SCORES || !a.b.qual || patl <= 104u;
+        uint8_t *slot = stg + MQR2 * 64u * 5u + lane * 128u; // 16 bytes of slack in front (LdsRow reads whole dwords around a byte), the bytes, slack
+        uint32_t head = 0;
+        wave_lds_sync();
+        if (want && SCORES && a.b.qual && in_lds) {
+            const uint8_t *q0 = a.b.qual + o0;
+            head = (uint32_t)((uintptr_t)q0 & 3u);
+            const uint32_t *__restrict__ src = reinterpret_cast<const uint32_t *>(q0 - head);
+            const uint32_t nd = (head + patl + 3u) >> 2;
+            for (uint32_t k = 0; k < nd; ++k) reinterpret_cast<uint32_t *>(slot + 16)[k] = src[k];
+        }
+        wave_lds_sync();
+        if (want && in_lds) flush_pending<W, SCORES, ALL>(a, s, sLL, LdsRow{stg, (uint32_t)(slot - stg) + 16u + head});
+        else if (want) flush_pending<W, SCORES, ALL>(a, s, sLL, GlobalRow{a.b.qual + o0});
+    } else if (DEFER) {
         for (uint32_t g = 0; g < 64; g += GL) {
             const uint64_t gb = __shfl(o0, (int)g), ge = __shfl(o1, (int)(g + GL - 1));
             const bool mine = lane >= g && lane < g + GL && elig && !ovf && s.p_n;
@@ -1204,11 +1356,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
             a.info[r] = s.info;
             if (SCORES) a.score[r] = s.iscore;
         }
-    } else if (!ALL && a.b.fresh && r < n) { // skipped or handed over: the record starts here (the wave matcher folds into it)
+    } else if (!ALL && fresh && r < n) { // skipped or handed over: the record starts here (whoever takes the read folds into it)
         a.info[r] = 0;
         if (SCORES) a.score[r] = -3.402823466e+38f;
     }
-    if (ALL && r < n) a.hit_cnt[r] = (elig && !ovf) ? s.nhit : 0u; // (a handed-over read: the wave matcher writes it)
+    if (ALL && r < n && (!PASS2 || (elig && !ovf))) a.hit_cnt[r] = (elig && !ovf) ? s.nhit : 0u; // (a handed-over read: who takes it writes it)
 
     // work counters: wave reduction, one atomic per wave and counter
 #if RH_PHASE_TIMING
@@ -1216,8 +1368,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W <= 5 ? 3 
     unsigned c[8] = {cR, l0_ ? ph_front - ph_start : 0u, l0_ ? s.tW : 0u, l0_ ? s.tD : 0u, l0_ ? s.tR : 0u, l0_ ? tQ : 0u, l0_ ? tS : 0u, l0_ ? PH_NOW() - ph_start : 0u};
     constexpr int NC = 8;
 #else
-    unsigned c[7] = {cR, s.cA & 15u, s.cB & 2047u, (s.cB >> 11) & 2047u, s.cA >> 16, s.cB >> 22, (s.cA >> 4) & 4095u};
-    constexpr int NC = 7;
+    // ([7]: reads matched outside the first pass -- real_hip_counters.handed_over)
+    unsigned c[8] = {cR, s.cA & 15u, s.cB & 2047u, (s.cB >> 11) & 2047u, s.cA >> 16, s.cB >> 22, (s.cA >> 4) & 4095u, PASS2 ? cR : 0u};
+    constexpr int NC = PASS2 ? 8 : 7;
     (void)ph_start; (void)ph_front;
 #endif
 #pragma unroll
@@ -1243,30 +1396,37 @@ static void launch_resident(void (*kernel)(MatchArgs), real_hip_ctx *ctx, const 
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 1) n_cu = 256;
     static const bool full_grid = getenv("REAL_HIP_FULL_GRID") != nullptr; // (experiments: one workgroup per 256 reads, every wave does one tile)
-    const uint64_t want = (a.b.n_reads + 255) / 256, have = full_grid ? want : (uint64_t)per_cu * (uint64_t)n_cu;
+    const uint64_t want = (a.b.n_reads + 255) / 256, have = full_grid ? want : (uint64_t)per_cu * (uint64_t)n_cu; // (second pass: its reads are a subset)
     dim3 grid((unsigned)(want < have ? want : have)), block(256);
     hipLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, a);
 }
 
-template <int W, int TK>
+template <int W, int TK, bool PASS2>
 static void launch_match_wt(real_hip_ctx *ctx, const MatchArgs &a, bool all)
 {
     const bool sc = ctx->prm.scores != 0;
     if (all) {
-        if (sc) launch_resident(match_kernel<W, true, true, TK>, ctx, a);
-        else    launch_resident(match_kernel<W, false, true, TK>, ctx, a);
+        if (sc) launch_resident(match_kernel<W, true, true, TK, PASS2>, ctx, a);
+        else if (!PASS2 || has_pass2<TK, false, true>()) launch_resident(match_kernel<W, false, true, TK, PASS2 && has_pass2<TK, false, true>()>, ctx, a);
     } else {
-        if (sc) launch_resident(match_kernel<W, true, false, TK>, ctx, a);
-        else    launch_resident(match_kernel<W, false, false, TK>, ctx, a);
+        if (sc) launch_resident(match_kernel<W, true, false, TK, PASS2>, ctx, a);
+        else if (!PASS2) launch_resident(match_kernel<W, false, false, TK, false>, ctx, a);
     }
 }
 #define RH_CAT2(a, b) a##b
 #define RH_CAT(a, b) RH_CAT2(a, b)
 void RH_CAT(rh_launch_match_w, RH_W)(real_hip_ctx *ctx, const MatchArgs &a, bool all)
 {
-    if (a.ix.fine == 3 && !a.ix.pbits) launch_match_wt<RH_W, 4>(ctx, a, all);
-    else if (a.ix.fine == 3) launch_match_wt<RH_W, 3>(ctx, a, all);
-    else if (a.ix.fine) launch_match_wt<RH_W, 1>(ctx, a, all);
-    else launch_match_wt<RH_W, 0>(ctx, a, all);
+    if (a.ix.fine == 3 && !a.ix.pbits) launch_match_wt<RH_W, 4, false>(ctx, a, all);
+    else if (a.ix.fine == 3) launch_match_wt<RH_W, 3, false>(ctx, a, all);
+    else if (a.ix.fine) launch_match_wt<RH_W, 1, false>(ctx, a, all);
+    else launch_match_wt<RH_W, 0, false>(ctx, a, all);
+}
+// the second pass over the reads the first one listed (bucket rows, parked hits: scores on or matchAll); nothing otherwise
+void RH_CAT(rh_launch_match2_w, RH_W)(real_hip_ctx *ctx, const MatchArgs &a, bool all)
+{
+    if (a.ix.fine != 3 || !(ctx->prm.scores || all)) return;
+    if (!a.ix.pbits) launch_match_wt<RH_W, 4, true>(ctx, a, all);
+    else launch_match_wt<RH_W, 3, true>(ctx, a, all);
 }
 uint32_t RH_CAT(rh_stage_bytes_w, RH_W)(int tk) { return stg_bytes(RH_W, tk); }

@@ -5,6 +5,7 @@
 
 #define RH_DECL_W(N)                                                                    \
     void rh_launch_match_w##N(real_hip_ctx *ctx, const MatchArgs &a, bool all);         \
+    void rh_launch_match2_w##N(real_hip_ctx *ctx, const MatchArgs &a, bool all);        \
     uint32_t rh_stage_bytes_w##N(int tk);
 RH_DECL_W(1) RH_DECL_W(2) RH_DECL_W(3) RH_DECL_W(4) RH_DECL_W(5) RH_DECL_W(6) RH_DECL_W(7) RH_DECL_W(8) RH_DECL_W(9) RH_DECL_W(10)
 void rh_launch_match_wave(real_hip_ctx *ctx, const MatchArgs &a, bool all);
@@ -17,6 +18,8 @@ int rh_launch_match(real_hip_ctx *ctx, const MatchArgs &args, bool all, int stat
     typedef uint32_t (*stage_fn)(int);
     static const launch_fn launch[RH_MAXW] = {rh_launch_match_w1, rh_launch_match_w2, rh_launch_match_w3, rh_launch_match_w4, rh_launch_match_w5,
                                               rh_launch_match_w6, rh_launch_match_w7, rh_launch_match_w8, rh_launch_match_w9, rh_launch_match_w10};
+    static const launch_fn launch2[RH_MAXW] = {rh_launch_match2_w1, rh_launch_match2_w2, rh_launch_match2_w3, rh_launch_match2_w4, rh_launch_match2_w5,
+                                               rh_launch_match2_w6, rh_launch_match2_w7, rh_launch_match2_w8, rh_launch_match2_w9, rh_launch_match2_w10};
     static const stage_fn stage[RH_MAXW] = {rh_stage_bytes_w1, rh_stage_bytes_w2, rh_stage_bytes_w3, rh_stage_bytes_w4, rh_stage_bytes_w5,
                                             rh_stage_bytes_w6, rh_stage_bytes_w7, rh_stage_bytes_w8, rh_stage_bytes_w9, rh_stage_bytes_w10};
     if (a.b.W < 1 || a.b.W > RH_MAXW) return rh_fail(ctx, REAL_HIP_E_UNSUPPORTED, "read longer than REAL_HIP_MAX_PATL", hipSuccess);
@@ -28,19 +31,26 @@ int rh_launch_match(real_hip_ctx *ctx, const MatchArgs &args, bool all, int stat
         while (gl > 1 && (uint64_t)gl * maxlen + 16 + 32 > region) gl >>= 1;
         a.b.gl = gl;
     }
-    // hand-over list of the reads the matcher leaves to the wave-cooperative kernel; [0] its length, [1] error flags
+    // hand-over lists: first pass -> second pass (ovf_list), -> wave-per-read kernel (ovf2_list).  The words of ovf_count:
+    // [0] length of ovf_list, [1] error flags, [2] tile counter of the first pass, [3] of the second, [4] length of ovf2_list
     if ((rc = rh_reserve(ctx, ctx->ovf_list, a.b.n_reads * 4))) return rc;
-    if ((rc = rh_reserve(ctx, ctx->ovf_count, 32))) return rc;
+    if ((rc = rh_reserve(ctx, ctx->ovf2_list, a.b.n_reads * 4))) return rc;
+    if ((rc = rh_reserve(ctx, ctx->ovf_count, 64))) return rc;
+    unsigned long long *oc = (unsigned long long *)ctx->ovf_count.p;
     a.ovf_list = (uint32_t *)ctx->ovf_list.p;
-    a.ovf_count = (unsigned long long *)ctx->ovf_count.p;
-    a.err_flags = (uint32_t *)((unsigned long long *)ctx->ovf_count.p + 1);
-    a.tile_ctr = (uint32_t *)((unsigned long long *)ctx->ovf_count.p + 2);
-    RH_HIP(ctx, hipMemsetAsync(ctx->ovf_count.p, 0, 32, ctx->stream));
+    a.ovf_count = oc;
+    a.err_flags = (uint32_t *)(oc + 1);
+    a.tile_ctr = (uint32_t *)(oc + 2);
+    a.tile_ctr2 = (uint32_t *)(oc + 3);
+    a.ovf2_list = (uint32_t *)ctx->ovf2_list.p;
+    a.ovf2_count = oc + 4;
+    RH_HIP(ctx, hipMemsetAsync(ctx->ovf_count.p, 0, 64, ctx->stream));
     rh_time_begin(ctx, ctx->stream, all ? REAL_HIP_K_MATCH_ALL : REAL_HIP_K_MATCH_UNIQUE);
     launch[a.b.W - 1](ctx, a, all);
     rh_time_end(ctx, ctx->stream);
     RH_HIP(ctx, hipGetLastError());
     rh_time_begin(ctx, ctx->stream, REAL_HIP_K_MATCH_REPEAT);
+    launch2[a.b.W - 1](ctx, a, all);
     rh_launch_match_wave(ctx, a, all);
     rh_time_end(ctx, ctx->stream);
     RH_HIP(ctx, hipGetLastError());

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
         __syncthreads();
     }
     const uint32_t lane = threadIdx.x & 63;
-    const uint64_t n_items = (uint64_t)*a.ovf_count;
+    const uint64_t n_items = (uint64_t)*a.ovf2_count;
     const uint64_t n_waves = (uint64_t)gridDim.x * 4;
     const uint32_t l = a.l, bb = a.b_bits, pbits = a.ix.pbits, pmask = pbits ? ((1u << pbits) - 1) : 0u, p16 = pbits < 16 ? pbits : 16;
     const uint64_t mb = (bb >= 64) ? ~0ull : ((1ull << bb) - 1);
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
     unsigned cR = 0, cL = 0, cP = 0, cC = 0, cS = 0, cH = 0, cV = 0;
 
     for (uint64_t it = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); it < n_items; it += n_waves) { // (wave-uniform trip count)
-        const uint64_t r = a.ovf_list[it];
+        const uint64_t r = a.ovf2_list[it];
         const uint64_t o0 = a.b.off ? a.b.off[r] : r * (uint64_t)a.b.upatl;
         const uint64_t span = a.b.off ? a.b.off[r + 1] - o0 : (uint64_t)a.b.upatl; // (64 bits: a span of 2^32 and more must not alias to a short read)
         const uint32_t patl = span > (uint64_t)REAL_HIP_MAX_PATL_LONG ? 0u : (uint32_t)span; // (0: not eligible below; the lane matcher has raised the error flag)

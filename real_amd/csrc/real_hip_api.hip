@@ -211,7 +211,7 @@ extern "C" void real_hip_destroy(real_hip_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     rh_comm_destroy(c);
     DevBuf *all[] = {&c->comm_counts, &c->comm_scratch, &c->text, &c->wild, &c->frag, &c->LL, &c->counters, &c->s_bases, &c->s_qual, &c->s_off, &c->s_info,
-                     &c->s_score, &c->maxpatl, &c->ovf_list, &c->ovf_count, &c->raw, &c->raw_count, &c->hit_cnt, &c->big_list, &c->all_cursor, &c->p_text, &c->p_nl, &c->p_scal, &c->p_spans, &c->p_off,
+                     &c->s_score, &c->maxpatl, &c->ovf_list, &c->ovf2_list, &c->ovf_count, &c->raw, &c->raw_count, &c->hit_cnt, &c->big_list, &c->all_cursor, &c->p_text, &c->p_nl, &c->p_scal, &c->p_spans, &c->p_off,
                      &c->p_len1, &c->p_bases, &c->p_qual, &c->keys_a,
                      &c->keys_b, &c->vals_a, &c->vals_b, &c->sort_tmp, &c->hit_off, &c->s_hits, &c->s_nflags};
     for (DevBuf *b : all) rh_release(*b);

@@ -120,8 +120,11 @@ struct MatchArgs {
     uint64_t raw_cap;
     uint32_t *hit_cnt;     // [n_reads] hits appended per read (every read of the batch is written)
     // reads handed from the matcher to the repeat kernel (scores on)
-    uint32_t *ovf_list;
+    uint32_t *ovf_list;    // first pass -> second pass (bucket rows, parked hits): reads that need more room than a lane of the first has
     unsigned long long *ovf_count;
+    uint32_t *ovf2_list;   // -> wave-per-read kernel: long equal ranges, long reads, what the second pass could not hold either
+    unsigned long long *ovf2_count;
+    uint32_t *tile_ctr2;   // the second pass' tile counter
     uint32_t *err_flags;   // bit 0: a read longer than the declared bound / offsets not monotone (nothing was staged for it)
     uint32_t *tile_ctr;    // the next tile of 64 reads to be handed out (match_kernel: the waves of a resident grid take tiles as they get done)
     double   filter_mult;
@@ -171,7 +174,7 @@ struct real_hip_ctx {
     DevBuf s_bases, s_qual, s_off, s_info, s_score, s_nflags;
     RhSlot slot[REAL_HIP_SLOTS];                    // submit / wait
     hipStream_t copy_stream = nullptr, down_stream = nullptr;
-    DevBuf maxpatl, ovf_list, ovf_count;
+    DevBuf maxpatl, ovf_list, ovf2_list, ovf_count;
     unsigned long long *h_state = nullptr; // pinned: {reads handed over, error flags} of the last launch of slot 0, slot 1, the synchronous calls
     // read ingestion (read_parse.hip)
     DevBuf p_text, p_nl, p_scal, p_spans, p_off, p_len1, p_bases, p_qual;

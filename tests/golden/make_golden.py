@@ -65,6 +65,14 @@ CASES = {
     # 250 bp reads (eight words per oriented read), seed 32, many mismatches allowed
     "l32_250bp_k8": dict(genome=dict(n=60000, seed=29, n_frag=2, n_runs=3, repeats=6, repeat_len=500), reads=[(150, 250, 0.02, 30)],
                          seedl=32, seedkmax=2, totalkmax=8, scores=1, n_list=0),
+    # scores on, near-copies of a read that differ from it in different seed segments and score an epsilon-step apart: the
+    # order of the update() calls decides the record (X, A | X, C | X, A, C ... ends NonUnique; grouped by window it
+    # would end Straight).  The compiled reference pins the event stream: list by list, ascending position inside a list.
+    "near_copies_xac": dict(make="near_copy", n=60000, seedl=32, seedkmax=2, totalkmax=3, scores=1, n_list=0),
+    "diverged_copies": dict(make="diverged", genome=dict(n=120000, seed=41, n_frag=2, n_runs=2), n_reads=200, patl=100, seed=42,
+                            seedl=32, seedkmax=2, totalkmax=3, scores=1, n_list=0),
+    "diverged_copies_l64": dict(make="diverged", genome=dict(n=160000, seed=43, n_frag=2), n_reads=150, patl=150, seed=44,
+                                seedl=64, seedkmax=2, totalkmax=5, scores=1, n_list=0),
 }
 
 
@@ -73,6 +81,13 @@ def sha(a: np.ndarray) -> str:
 
 
 def make_inputs(case):
+    if case.get("make") == "near_copy":
+        g, b, _ = synth.near_copy_case(n=case["n"], seedl=case["seedl"])
+        return g, b
+    if case.get("make") == "diverged":
+        g = synth.random_genome(**case["genome"])
+        b = synth.diverged_copy_reads(g, case["n_reads"], case["patl"], case["seedl"], seed=case["seed"])     # (plants the copies into g)
+        return g, b
     g = synth.random_genome(**case["genome"])
     batches = [synth.sample_reads(g, n, patl, err, seed, n_read_prob=case.get("n_read_prob", 0.0))
                for (n, patl, err, seed) in case["reads"]]
