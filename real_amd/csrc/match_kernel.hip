@@ -46,6 +46,7 @@
 #ifndef RH_PHASE_TIMING
 #define RH_PHASE_TIMING 0
 #endif
+
 #if RH_PHASE_TIMING
 #define PH_NOW() ((unsigned)__builtin_amdgcn_s_memrealtime())
 #else
@@ -910,7 +911,6 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
         unsigned ph1 = PH_NOW();
         s.tW += ph1 - ph0;
 #endif
-        if (li + 1 < NL) ISSUE_ROWS(la + 1); // the next list's rows are in flight while this one is decoded and drained
         // owners: directory of the row, then the entries of their key group
         const bool mine = act && !(s.p_n == PEND_OVF) && !(RH_ABLATE & 8);
         const uint8_t *rowb = rowbuf + lane * 128;
@@ -983,6 +983,9 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
         // list).  A lane is of one kind for the whole list, so the order of its own entries is what it was.
         U64x2 pre = {0ull, 0ull};
         if (e_ovf && e_cnt) pre = load2(reinterpret_cast<const uint64_t *>(a.ix.ent[la] + e_base)); // (two entries; the array is padded by one)
+        // the next list's rows are in flight while this one is decoded and drained (requested behind the two entries above:
+        // loads come back in the order they were issued; in front of them it measured the same)
+        if (li + 1 < NL) ISSUE_ROWS(la + 1);
         // a survivor of the partner filter goes to the lane's queue; a window that is in the queue already only gets this
         // list's bit set (the lane's last queue entry is kept in registers: for it nothing is read back).  A lane that needs
         // more than MQRn queue slots for one strand (repeat-rich loci only) hands its read over: the queues are drained
