@@ -23,7 +23,8 @@ W = (patl + 31) // 32                                      # match_kernel<W, sco
 stats = os.path.join(pdir, "trace", "trace_kernel_stats.csv")
 kname = None
 for r in csv.DictReader(open(stats)):
-    if r["Name"].startswith("void match_kernel<%d, true, %s," % (W, all_flag)):
+    # (the first pass: `..., false>`; the same template with `true` is the second pass over the few reads that outgrow a lane)
+    if r["Name"].startswith("void match_kernel<%d, true, %s," % (W, all_flag)) and r["Name"].rstrip().endswith("false>(MatchArgs)"):
         kname, avg_ms, calls = r["Name"], float(r["AverageNs"]) / 1e6, int(r["Calls"])
 assert kname, "match kernel not in " + stats
 sel = kname[len("void "):]
