@@ -360,11 +360,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
             return true;
         };
         const uint8_t *const qrow = !a.b.qual ? nullptr : (q_lds ? (const uint8_t *)qst + 16 : a.b.qual + o0);
-        // ---- few candidates (a read on a handful of copies of a locus -- what most of the reads that come here are): all twelve
-        // equal ranges in ONE round, lane = (strand, list, entry) in the canonical order.  One chain of dependent loads (entry
-        // -> text -> verdict -> score) per read instead of twelve, and the survivors are folded in lane order = strand, list,
-        // entry = the reference's order of update() calls.  (Without scores the 12-call driver may skip lists 1..5 of a strand
-        // after list 0, matchUniqueImplementation.cpp:434-436: that mode walks the lists one by one below.)
+        // ---- scores on / matchAll: the twelve equal ranges are ONE sequence of candidates in the canonical order (strand, list,
+        // entry), taken 64 at a time, lane = candidate.  A read on a handful of copies of a locus -- what most of the reads
+        // that come here are -- is one round: one chain of dependent loads (entry -> text -> verdict -> score) instead of
+        // twelve; a read with a long equal range takes as many rounds as its candidates need, not one per list and 64 entries.
+        // The survivors are folded in lane order, round by round = strand, list, entry = the reference's order of update()
+        // calls.  (Without scores the 12-call driver may skip lists 1..5 of a strand after list 0,
+        // matchUniqueImplementation.cpp:434-436: that mode walks the lists one by one below.)
         uint32_t c_mine = lane < 12 ? RL.cnt : 0u, c_before = 0, c_total = 0;
         {
             uint32_t run = 0;
@@ -376,44 +378,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
             }
             c_total = run;
         }
-        if ((SCORES || ALL) && c_total <= 64u) {
-            // the (strand, list) whose range lane `lane` falls into: the last q with before[q] <= lane
-            uint32_t src = 0;
-#pragma unroll
-            for (int q = 1; q < 12; ++q)
-                if ((uint32_t)__shfl((int)c_before, q) <= lane) src = (uint32_t)q;
-            WaveRange R;
-            {
-                const uint64_t e = (uint64_t)(uintptr_t)RL.E, w = (uint64_t)(uintptr_t)RL.row;
-                R.E = (const uint2 *)(uintptr_t)(((uint64_t)(uint32_t)__shfl((int)(e >> 32), (int)src) << 32) | (uint32_t)__shfl((int)e, (int)src));
-                R.row = (const uint32_t *)(uintptr_t)(((uint64_t)(uint32_t)__shfl((int)(w >> 32), (int)src) << 32) | (uint32_t)__shfl((int)w, (int)src));
-                R.lo = (uint32_t)__shfl((int)RL.lo, (int)src); R.cnt = (uint32_t)__shfl((int)RL.cnt, (int)src); R.key = (uint32_t)__shfl((int)RL.key, (int)src);
-                R.mode = (uint32_t)__shfl((int)RL.mode, (int)src); R.partner = (uint32_t)__shfl((int)RL.partner, (int)src); R.counted = (uint32_t)__shfl((int)RL.counted, (int)src);
-            }
+        if (SCORES || ALL) {
             if (lane < 12) { cL++; cP += RL.cnt; cC += RL.counted; }
-            const uint32_t inv = src >= 6 ? 1u : 0u, la = src - 6 * inv;
-            const uint32_t i = lane - (uint32_t)__shfl((int)c_before, (int)src);
-            uint32_t pos = 0, total = 0, frag = 0, first = 0;
-            const bool hit = candidate(R, i, lane < c_total, inv, la, pos, total, frag, first);
-            float sc = 1.0f; // ComputeScore<...,false>, ComputeScore.hpp:31-45
-            // (a location reached through several lists is scored by each of its lanes: the lanes run the loop together anyway)
-            if (SCORES && hit) sc = long_score(sLL, T, inv ? sR : sO, pos, patl, qrow, inv);
-            if (ALL) {
-                // unifyMatches (matchAllImplementation.cpp:150-161) removes exact duplicates: a (strand, pos) is kept
-                // from the first list whose two segments are mismatch free
-                const bool keep = hit && first == la;
-                if (keep) {
-                    const unsigned long long slot = wave_append_slot(a.raw_count); // ballot + prefix popcount, one atomic
-                    if (slot < a.raw_cap) a.raw[slot] = make_uint4((uint32_t)r, pos, __float_as_uint(sc), total | (inv << 8) | (frag << 16));
+#pragma unroll 1
+            for (uint32_t f0 = 0; f0 < c_total; f0 += 64) {
+                const uint32_t f = f0 + lane;
+                // the (strand, list) whose range candidate f falls into: the last q with before[q] <= f
+                uint32_t src = 0;
+#pragma unroll
+                for (int q = 1; q < 12; ++q)
+                    if ((uint32_t)__shfl((int)c_before, q) <= f) src = (uint32_t)q;
+                WaveRange R;
+                {
+                    const uint64_t e = (uint64_t)(uintptr_t)RL.E, w = (uint64_t)(uintptr_t)RL.row;
+                    R.E = (const uint2 *)(uintptr_t)(((uint64_t)(uint32_t)__shfl((int)(e >> 32), (int)src) << 32) | (uint32_t)__shfl((int)e, (int)src));
+                    R.row = (const uint32_t *)(uintptr_t)(((uint64_t)(uint32_t)__shfl((int)(w >> 32), (int)src) << 32) | (uint32_t)__shfl((int)w, (int)src));
+                    R.lo = (uint32_t)__shfl((int)RL.lo, (int)src); R.cnt = (uint32_t)__shfl((int)RL.cnt, (int)src); R.key = (uint32_t)__shfl((int)RL.key, (int)src);
+                    R.mode = (uint32_t)__shfl((int)RL.mode, (int)src); R.partner = (uint32_t)__shfl((int)RL.partner, (int)src); R.counted = (uint32_t)__shfl((int)RL.counted, (int)src);
                 }
-                nhit += (uint32_t)__popcll(__ballot(keep));
-            } else {
-                unsigned long long hm = __ballot(hit);
-                while (hm) { // UpdateUniqueInfo::update in candidate order; the record is wave-uniform
-                    const int j = __ffsll((long long)hm) - 1;
-                    hm &= hm - 1;
-                    fold_update<SCORES>(__shfl((int)inv, j) != 0, a.t.fileid, (uint32_t)__shfl((int)pos, j), (unsigned)__shfl((int)total, j), __shfl(sc, j), eps,
-                                        (unsigned)__shfl((int)frag, j), info, iscore);
+                const uint32_t inv = src >= 6 ? 1u : 0u, la = src - 6 * inv;
+                const uint32_t i = f - (uint32_t)__shfl((int)c_before, (int)src);
+                uint32_t pos = 0, total = 0, frag = 0, first = 0;
+                const bool hit = candidate(R, i, f < c_total, inv, la, pos, total, frag, first);
+                float sc = 1.0f; // ComputeScore<...,false>, ComputeScore.hpp:31-45
+                // (a location reached through several lists is scored by each of its lanes: the lanes run the loop together anyway)
+                if (SCORES && hit) sc = long_score(sLL, T, inv ? sR : sO, pos, patl, qrow, inv);
+                if (ALL) {
+                    // unifyMatches (matchAllImplementation.cpp:150-161) removes exact duplicates: a (strand, pos) is kept
+                    // from the first list whose two segments are mismatch free
+                    const bool keep = hit && first == la;
+                    if (keep) {
+                        const unsigned long long slot = wave_append_slot(a.raw_count); // ballot + prefix popcount, one atomic
+                        if (slot < a.raw_cap) a.raw[slot] = make_uint4((uint32_t)r, pos, __float_as_uint(sc), total | (inv << 8) | (frag << 16));
+                    }
+                    nhit += (uint32_t)__popcll(__ballot(keep));
+                } else {
+                    unsigned long long hm = __ballot(hit);
+                    while (hm) { // UpdateUniqueInfo::update in candidate order; the record is wave-uniform
+                        const int j = __ffsll((long long)hm) - 1;
+                        hm &= hm - 1;
+                        fold_update<SCORES>(__shfl((int)inv, j) != 0, a.t.fileid, (uint32_t)__shfl((int)pos, j), (unsigned)__shfl((int)total, j), __shfl(sc, j), eps,
+                                            (unsigned)__shfl((int)frag, j), info, iscore);
+                    }
                 }
             }
         } else
