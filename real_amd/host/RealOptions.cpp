@@ -1,10 +1,12 @@
 #include "RealOptions.hpp"
 
+#include <cstdio>
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
 #include <stdexcept>
 #include <vector>
+#include <unistd.h>
 
 bool RealOptions::isFastQ(const std::string &filename)
 {
@@ -17,10 +19,15 @@ bool RealOptions::isFastQ(const std::string &filename)
     throw std::runtime_error("Unable to determine type of pattern file.");
 }
 
+SpoolFile::~SpoolFile()
+{
+    if (!path.empty()) unlink(path.c_str());
+}
+
 void RealOptions::printHelp() const
 {
     std::cerr << "Options:\n"
-              << "-t <textfilename>\n-p <patternfilename>\n-o <outputfilename>\n"
+              << "-t <textfilename: a .fa file, or a directory searched for .fa files>\n-p <patternfilename, - = standard input>\n-o <outputfilename, - = standard output>\n"
               << "-s <maximum number of errors in seed, default=2>\n"
               << "-e <total maximum number of errors, default=5>\n"
               << "-l <length of seed, default=32>\n"
@@ -92,7 +99,39 @@ RealOptions::RealOptions(int argc, char *argv[])
     if (!patternfilename.size()) throw std::runtime_error("Mandatory argument -p (pattern file name) is not given.");
     if (!outputfilename.size()) throw std::runtime_error("Mandatory argument -o (output file name) is not given.");
     if (fracmem > 1.0) fracmem = 1.0;
+    if (patternfilename == "-") {
+        // Reads from standard input (RealOptions.cpp:418-426, real.cpp:240-257).  The reference rewrites them into its
+        // temporary pattern file because it reads the patterns once per genome block and once more for the output; so does
+        // this driver, through a spool file of the text as it came (the rewritten binary format is out of scope).
+        const char *tmp = getenv("TMPDIR");
+        std::string name = std::string(tmp && *tmp ? tmp : "/tmp") + "/real_stdin_XXXXXX";
+        std::vector<char> path(name.begin(), name.end());
+        path.push_back(0);
+        const int fd = mkstemp(path.data());
+        if (fd < 0) throw std::runtime_error("Unable to create a temporary file for the patterns from standard input.");
+        stdin_spool.path = path.data();
+        std::cerr << "Reading patterns from stdin, writing them to temporary file " << stdin_spool.path << std::endl;
+        std::vector<char> buf((size_t)8 << 20);
+        size_t got;
+        bool ok = true;
+        while (ok && (got = fread(buf.data(), 1, buf.size(), stdin)) > 0)
+            for (size_t off = 0; ok && off < got;) {
+                const ssize_t w = write(fd, buf.data() + off, got - off);
+                if (w <= 0) ok = false; else off += (size_t)w;
+            }
+        close(fd);
+        if (!ok) throw std::runtime_error("Failed to write the patterns from standard input to the temporary file.");
+        patternfilename = stdin_spool.path;
+        rewritepatterns = true;
+    }
     fastq = isFastQ(patternfilename);
+    if (fastq && !qualityOffset && !stdin_spool.empty()) {
+        // real.cpp:248-257: no detection on standard input, Illumina GA assumed
+        std::cerr << "WARNING: automatic quality offset detection not supported when" << std::endl;
+        std::cerr << "         reading patterns from standard input. Assuming input" << std::endl;
+        std::cerr << "         was produced by an Illumina  GA (i.e. -Q 64)" << std::endl;
+        qualityOffset = 64;
+    }
     std::cerr << "pattern file is " << (fastq ? "FASTQ" : "FASTA") << std::endl;
     // clamps of RealOptions.cpp:434-453
     if (seedl > 64) { seedl = 64; std::cerr << "reduced seed size to " << seedl << " to not exceed 64." << std::endl; }

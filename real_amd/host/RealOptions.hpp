@@ -4,6 +4,16 @@
 #include <stdint.h>
 #include <string>
 
+// a file that is removed with its owner (also when the owner's constructor throws behind it)
+struct SpoolFile {
+    std::string path;
+    SpoolFile() {}
+    ~SpoolFile();
+    SpoolFile(const SpoolFile &) = delete;
+    SpoolFile &operator=(const SpoolFile &) = delete;
+    bool empty() const { return path.empty(); }
+};
+
 struct RealOptions {
     // defaults: RealOptions.hpp:27-36
     std::string textfilename, patternfilename, outputfilename;
@@ -21,6 +31,7 @@ struct RealOptions {
     double similarity = 0.995, err = 0.0, trans = 0.71, gc = 0.41, gcmut_bias = 2.0; // Scoring.cpp:204-208
     bool gaps = false;
     bool fastq = false;
+    SpoolFile stdin_spool;    // -p -: the file the reads from standard input were written to (removed when the options go)
     // this build
     int device = 0;           // -device: first HIP device
     int gpus = 1;             // -gpus: read batches are dealt round-robin to this many devices
@@ -35,6 +46,7 @@ struct RealOptions {
 
     RealOptions() {}
     RealOptions(int argc, char *argv[]); // throws std::runtime_error like the reference
+
     void printHelp() const;
     static bool isFastQ(const std::string &filename); // RealOptions.cpp:43-72
     double getFilterValue(unsigned patl) const { return filter_mult * patl; } // RealOptions.hpp:74-77

@@ -262,3 +262,22 @@ def test_real_cli_genome_directory_of_two_files(ora, tmp_path, extra):
                                         "-" if h["inverted"] else "+", g.frag_names[int(h["frag"])],
                                         str(int(h["pos"]) - int(g.frag_start[int(h["frag"])]) + 1), "", str(int(h["k"]))]))
         assert got == want
+
+
+@pytest.mark.parametrize("fastq", [True, False])
+def test_real_cli_patterns_from_stdin(ora, tmp_path, fastq):
+    """`real -p -`: the reads piped in give the lines the read file gives (RealOptions.cpp:418-426)."""
+    g = synth.random_genome(80_000, seed=41, n_frag=3, n_runs=6, repeats=15)
+    b = synth.sample_reads(g, 1200, 100, 0.02, seed=49, n_read_prob=0.0005)
+    fa, rd = write_inputs(tmp_path, g, b, fastq)
+    out_file, out_pipe = str(tmp_path / "file.tsv"), str(tmp_path / "pipe.tsv")
+    base = [REAL, "-t", fa, "-e", "3", "-s", "2", "-l", "32", "-q", "1", "-Q", "33", "-chunk", "50000"]
+    r = subprocess.run(base + ["-p", rd, "-o", out_file], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    env = dict(os.environ, TMPDIR=str(tmp_path))
+    r = subprocess.run(base + ["-p", "-", "-o", out_pipe], stdin=open(rd, "rb"), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert "Reading patterns from stdin" in r.stderr.decode() and not list(tmp_path.glob("real_stdin_*"))
+    info, score = oracle_unique(ora, g, b, 32, 2, 3, 1, 0, fasta=not fastq)
+    want = expected_unique(ora, g, b, info, score, 1)
+    assert open(out_pipe).read().split("\n")[:-1] == want == open(out_file).read().split("\n")[:-1]

@@ -671,3 +671,57 @@ def test_two_genome_files_fold_through_the_file_id(ora, scores, kind, pb, seedl)
     assert (uniq & (fi == 0)).sum() > 500 and (uniq & (fi == 1)).sum() > 400, "both files have uniquely aligned reads"
     assert (st[-200:] == 4).sum() >= 150, "reads of the shared stretch are NonUnique through the file id"
     m.close()
+
+
+@pytest.mark.parametrize("scores", [1, 0])
+def test_second_pass_across_index_blocks_and_fresh_records(ora, scores):
+    """Reads on six copies of a locus, twice: six copies inside the first index block and six more inside the third.  The
+    first pass of the lane matcher hands such a read on (more than four locations), the second pass folds into the record
+    the first pass started (block 1: `fresh` -- the arrays hold garbage that would win every fold) or the previous blocks
+    left (blocks 2, 3): the records compose across the blocks exactly as the reference's uniqueinfo[] does
+    (ListSetBlockReader.hpp:24-52), whoever matched the read in which block."""
+    rng = np.random.default_rng(77)
+    G = 96_000
+    sym = rng.integers(0, 4, size=G, dtype=np.uint8)
+    src = 2_000
+    for c in range(1, 6):
+        sym[src + 5_000 * c: src + 5_000 * c + 1000] = sym[src:src + 1000]
+    for c in range(6):
+        sym[66_000 + 4_500 * c: 66_000 + 4_500 * c + 1000] = sym[src:src + 1000]
+    frag = np.array([0, 50_000, G], dtype=np.uint64)
+    reads = []
+    for i in range(150):
+        r = sym[src + 20 + 5 * i: src + 120 + 5 * i].copy()
+        if i % 2:
+            r = synth.revcomp(r)
+        if i % 4 == 0:
+            r[(13 * i) % 100] = (r[(13 * i) % 100] + 1) & 3
+        reads.append(r)
+    extra = synth.sample_reads(synth.Genome(sym=sym, frag_start=frag), 400, 100, 0.02, seed=78)
+    bases = np.concatenate([np.concatenate(reads), extra.bases]).astype(np.uint8)
+    n = 150 + extra.n_reads
+    qual = rng.integers(3, 40, size=bases.shape[0]).astype(np.uint8)
+    offsets = np.arange(n + 1, dtype=np.uint64) * np.uint64(100)
+    n_list = 32_000
+    p = ora.make_params(seedl=16, seedkmax=2, totalkmax=3, scores=scores)
+    oinfo, oscore, octr = _oracle_unique(ora, None, sym, frag, 16, n_list, p, bases, qual, offsets)
+    m = UniqueMatcher(_opts(16, 2, 3, scores), prefix_bits=13, table_kind=3)
+    m.set_text_symbols(0, sym, frag)
+    info = np.full(n, 0x7123456789abcdef, dtype=np.uint64)
+    score = np.full(n, 1e30, dtype=np.float32) if scores else None
+    first, nxt, blocks = 0, True, 0
+    m.counters(reset=True)
+    while nxt:
+        cnt, nxt = m.build_index_block(first, n_list)
+        assert m.table_kind == 3
+        first += cnt
+        m.match_unique(bases, qual, offsets, info=info, score=score, fresh=(blocks == 0))
+        blocks += 1
+    assert blocks == 3
+    _compare_unique(info, score, oinfo, oscore if scores else None, scores)
+    c = m.counters()
+    for kk in ("reads", "lookups", "candidates", "seedpass", "hits"):
+        assert c[kk] == octr[kk], (kk, c[kk], octr[kk])
+    if scores:
+        assert c["handed_over"] >= 200, c            # the 150 reads on the copies, in two of the three blocks
+    m.close()

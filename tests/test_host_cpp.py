@@ -111,6 +111,26 @@ def test_realoptions_cpp(selftest, tmp_path):
     assert subprocess.call([selftest, "options", "-t", "g.fa", "-p", str(fq), "-o"], stderr=subprocess.DEVNULL) != 0
 
 
+def test_realoptions_patterns_from_stdin(selftest, tmp_path):
+    """-p - (RealOptions.cpp:418-426, real.cpp:240-257): the patterns come from standard input; they are spooled into a
+    temporary file (the driver reads them once per genome block and once more for the output, as the reference does through
+    its rewritten pattern file), the format is taken from the first character, and a FASTQ without -Q is taken to be
+    Illumina GA (offset 64) with the reference's warning.  The spool file is gone when the options are."""
+    env = dict(os.environ, TMPDIR=str(tmp_path))
+    r = subprocess.run([selftest, "options", "-t", "g.fa", "-p", "-", "-o", "out"], input=b"@a\nACGT\n+\nhhhh\n", env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    out = r.stdout.decode().split()
+    assert out[1].startswith(str(tmp_path)) and "real_stdin_" in out[1] and out[8] == "64" and out[11] == "1"
+    assert b"Assuming input" in r.stderr and not os.path.exists(out[1])
+    r = subprocess.run([selftest, "options", "-t", "g.fa", "-p", "-", "-o", "out", "-Q", "33"], input=b">a\nACGT\n", env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    out = r.stdout.decode().split()
+    assert r.returncode == 0 and out[8] == "33" and out[11] == "0" and b"Assuming input" not in r.stderr
+    r = subprocess.run([selftest, "options", "-t", "g.fa", "-p", "-", "-o", "out"], input=b"", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode != 0 and not list(tmp_path.glob("real_stdin_*"))       # empty input: the reference's error, and no file left behind
+
+
 def test_fast_score_formatter_equals_printf(selftest):
     """the score column: fastformat::fmt_g6 (integer arithmetic) against printf's %g -- which is what the reference's
     operator<<(float) prints -- on random bit patterns, score-like values, integers and both sides of every power of ten"""
