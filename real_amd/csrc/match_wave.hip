@@ -214,8 +214,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
     __shared__ double sLL[SCORES ? RH_LL_SLOTS : 1];
     __shared__ uint64_t sLong[4][2][LONG ? WV_NWL : WV_W]; // per wave: the words of its read, straight and reverse-complemented
     __shared__ __attribute__((aligned(16))) uint8_t sQual[4][16 + QL + 16]; // ... the qualities of the read (16 bytes in front and behind: LdsRow reads whole dwords)
-    __shared__ uint32_t sMemoPos[4][WV_MEMO];
-    __shared__ float sMemoSc[4][WV_MEMO];
+    __shared__ uint32_t sMemoPos[4][2][WV_MEMO]; // (per wave and strand)
+    __shared__ float sMemoSc[4][2][WV_MEMO];
     if (SCORES) {
         for (int i = threadIdx.x; i < 1024; i += 256) sLL[i] = a.LL[i];
         if (threadIdx.x == 0) sLL[RH_LL_ZERO] = 0.0;
@@ -380,29 +380,55 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
         }
         if (SCORES || ALL) {
             if (lane < 12) { cL++; cP += RL.cnt; cC += RL.counted; }
+            // where the twelve ranges start in the sequence: wave-uniform, compared in registers round after round
+            uint32_t starts[12];
+#pragma unroll
+            for (int q = 0; q < 12; ++q) starts[q] = (uint32_t)__builtin_amdgcn_readlane((int)c_before, q);
+            WaveRange R = RL;
+            uint32_t src_have = lane < 12 ? lane : 0xffffffffu; // the range whose description this lane holds in R
+            uint32_t nmemo0 = 0, nmemo1 = 0; // scored locations of the read, per strand (wave-uniform)
 #pragma unroll 1
             for (uint32_t f0 = 0; f0 < c_total; f0 += 64) {
                 const uint32_t f = f0 + lane;
-                // the (strand, list) whose range candidate f falls into: the last q with before[q] <= f
+                // the (strand, list) whose range candidate f falls into: the last q with starts[q] <= f
                 uint32_t src = 0;
 #pragma unroll
-                for (int q = 1; q < 12; ++q)
-                    if ((uint32_t)__shfl((int)c_before, q) <= f) src = (uint32_t)q;
-                WaveRange R;
-                {
+                for (int q = 1; q < 12; ++q) src = starts[q] <= f ? (uint32_t)q : src;
+                // its description comes from the lane that looked it up -- not again while a lane stays inside one range
+                // (a long equal range is many rounds of the same list)
+                if (__any(src != src_have)) {
                     const uint64_t e = (uint64_t)(uintptr_t)RL.E, w = (uint64_t)(uintptr_t)RL.row;
                     R.E = (const uint2 *)(uintptr_t)(((uint64_t)(uint32_t)__shfl((int)(e >> 32), (int)src) << 32) | (uint32_t)__shfl((int)e, (int)src));
                     R.row = (const uint32_t *)(uintptr_t)(((uint64_t)(uint32_t)__shfl((int)(w >> 32), (int)src) << 32) | (uint32_t)__shfl((int)w, (int)src));
                     R.lo = (uint32_t)__shfl((int)RL.lo, (int)src); R.cnt = (uint32_t)__shfl((int)RL.cnt, (int)src); R.key = (uint32_t)__shfl((int)RL.key, (int)src);
                     R.mode = (uint32_t)__shfl((int)RL.mode, (int)src); R.partner = (uint32_t)__shfl((int)RL.partner, (int)src); R.counted = (uint32_t)__shfl((int)RL.counted, (int)src);
+                    src_have = src;
                 }
                 const uint32_t inv = src >= 6 ? 1u : 0u, la = src - 6 * inv;
                 const uint32_t i = f - (uint32_t)__shfl((int)c_before, (int)src);
                 uint32_t pos = 0, total = 0, frag = 0, first = 0;
                 const bool hit = candidate(R, i, f < c_total, inv, la, pos, total, frag, first);
                 float sc = 1.0f; // ComputeScore<...,false>, ComputeScore.hpp:31-45
-                // (a location reached through several lists is scored by each of its lanes: the lanes run the loop together anyway)
-                if (SCORES && hit) sc = long_score(sLL, T, inv ? sR : sO, pos, patl, qrow, inv);
+                // A location reached through several lists in ONE round is scored by each of its lanes (they run the loop
+                // together anyway); the scores of a round are kept for the rounds to come (the same window, the same score:
+                // a read with a long equal range finds its locus again in every later list, a round each)
+                bool scored = false;
+                if (SCORES && hit && !memo_score(sMemoPos[threadIdx.x >> 6][inv], sMemoSc[threadIdx.x >> 6][inv], inv ? nmemo1 : nmemo0, pos, sc)) {
+                    sc = long_score(sLL, T, inv ? sR : sO, pos, patl, qrow, inv);
+                    scored = true;
+                }
+                if (SCORES) {
+                    const unsigned long long sm0 = __ballot(scored && !inv), sm1 = __ballot(scored && inv);
+                    if (sm0 | sm1) {
+                        const unsigned long long below = (1ull << lane) - 1ull;
+                        const uint32_t slot = inv ? nmemo1 + (uint32_t)__popcll(sm1 & below) : nmemo0 + (uint32_t)__popcll(sm0 & below);
+                        if (scored && slot < WV_MEMO) { sMemoPos[threadIdx.x >> 6][inv][slot] = pos; sMemoSc[threadIdx.x >> 6][inv][slot] = sc; }
+                        nmemo0 = min(WV_MEMO, nmemo0 + (uint32_t)__popcll(sm0));
+                        nmemo1 = min(WV_MEMO, nmemo1 + (uint32_t)__popcll(sm1));
+                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
                 if (ALL) {
                     // unifyMatches (matchAllImplementation.cpp:150-161) removes exact duplicates: a (strand, pos) is kept
                     // from the first list whose two segments are mismatch free
@@ -449,7 +475,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
                     const bool hit = candidate(R, i, i < R.cnt, (uint32_t)inv, (uint32_t)la, pos, total, frag, first);
                     bool scored = false;
                     float sc = 1.0f; // ComputeScore<...,false>, ComputeScore.hpp:31-45
-                    if (SCORES && hit && !memo_score(sMemoPos[threadIdx.x >> 6], sMemoSc[threadIdx.x >> 6], nmemo, pos, sc)) {
+                    if (SCORES && hit && !memo_score(sMemoPos[threadIdx.x >> 6][inv], sMemoSc[threadIdx.x >> 6][inv], nmemo, pos, sc)) {
                         sc = long_score(sLL, T, inv ? sR : sO, pos, patl, qrow, (uint32_t)inv);
                         scored = true;
                     }
@@ -457,7 +483,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
                         const unsigned long long sm = __ballot(scored);
                         if (sm) {
                             const uint32_t slot = nmemo + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull));
-                            if (scored && slot < WV_MEMO) { sMemoPos[threadIdx.x >> 6][slot] = pos; sMemoSc[threadIdx.x >> 6][slot] = sc; }
+                            if (scored && slot < WV_MEMO) { sMemoPos[threadIdx.x >> 6][inv][slot] = pos; sMemoSc[threadIdx.x >> 6][inv][slot] = sc; }
                             nmemo = min(WV_MEMO, nmemo + (uint32_t)__popcll(sm));
                             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                             __builtin_amdgcn_wave_barrier();
