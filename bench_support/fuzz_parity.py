@@ -52,7 +52,9 @@ def main():
         if rng.random() < args.copy_prob:  # exact copies of a segment: reads on them have several locations
             L = int(min(rng.choice([300, 1000]), n // 8))
             src = int(rng.integers(0, n - L))
-            for _ in range(int(rng.integers(1, 7))):
+            # (1..6 copies: the first pass' and, from five on, the second pass' reads; now and then a dozen or thirty: the second
+            # pass at its limit and the wave-per-read kernel)
+            for _ in range(int(rng.choice([1, 2, 3, 4, 5, 6, 6, 8, 13, 26, 31]))):
                 d = int(rng.integers(0, n - L))
                 g.sym[d:d + L] = g.sym[src:src + L]
         nreads = int(rng.choice([64, 257, 1500]))

@@ -70,8 +70,8 @@ static_assert(BKX_OFF + 256u <= stg_bytes(4, 3) && ROWBUF_OFF % 16 == 0 && QUEUE
 // pass -- reads on five and more copies of a locus -- are matched once more by the same lane-per-read code with room for
 // NPEND2 parked locations and MQR2 queue slots per strand (registers and LDS of an instance that only sees a few per cent
 // of the reads).  What outgrows that too, long equal ranges and long reads go to the wave-per-read kernel.
-#define NPEND2 12
-#define MQR2 16u
+#define NPEND2 24
+#define MQR2 24u
 __host__ __device__ constexpr uint32_t stg_bytes2() { return MQR2 * 64u * 5u + 64u * 128u + 256u; }
 #define STG_PAD 16u
 #ifndef RH_KEEP_TW_MAXW
@@ -79,8 +79,8 @@ __host__ __device__ constexpr uint32_t stg_bytes2() { return MQR2 * 64u * 5u + 6
 #endif
 #define NPEND 4      // verified locations a lane parks until their scores are computed (flush_pending), each with the
                      // set of lists through which it was reached (= its update() events)
-#define SLOT_NONE 15u
-#define SLOT_BIG 14u   // cslot of a read that is handed over because of a long equal range (not for want of room: the second pass would be no help)
+#define SLOT_NONE 31u
+#define SLOT_BIG 30u   // cslot of a read that is handed over because of a long equal range (not for want of room: the second pass would be no help)
 #define PEND_OVF 0xffu // p_n of a read that is handed over to the wave-cooperative matcher (match_wave.hip)
 #define BIG_T 48u      // an equal range / bucket scan longer than this many entries is not walked by one lane: hand-over
 
@@ -239,8 +239,10 @@ __device__ __forceinline__ void flush_pending(const MatchArgs &a, LaneState<W, S
         return;
     }
     if (s.p_n < 2) return;
-    // rank of every location by (strand, position); ord = the locations in that order, 4 bits each
-    uint64_t ord = 0;
+    // rank of every location by (strand, position); ord = the locations in that order, 5 bits each, twelve to a word
+    static_assert(NP <= 24, "two words of twelve ranks");
+    uint64_t ord0 = 0, ord1 = 0;
+    auto ord_at = [&](uint32_t rk) { return (uint32_t)((rk < 12 ? ord0 >> (5 * rk) : ord1 >> (5 * (rk - 12))) & 31u); };
 #pragma unroll
     for (uint32_t j = 0; j < (uint32_t)NP; ++j) {
         const uint64_t kj = ((uint64_t)((s.p_meta[j] >> 8) & 1u) << 32) | s.p_pos[j];
@@ -250,7 +252,8 @@ __device__ __forceinline__ void flush_pending(const MatchArgs &a, LaneState<W, S
             const uint64_t ki = ((uint64_t)((s.p_meta[i] >> 8) & 1u) << 32) | s.p_pos[i];
             if (i != j && i < s.p_n && (ki < kj || (ki == kj && i < j))) rank++;
         }
-        if (j < s.p_n) ord |= (uint64_t)j << (4 * rank);
+        if (j < s.p_n && rank < 12) ord0 |= (uint64_t)j << (5 * rank);
+        if (j < s.p_n && rank >= 12) ord1 |= (uint64_t)j << (5 * (rank - 12));
     }
     if (NP <= 4) {
         // the event sequence first (2 bits per event = its location; at most 4 x 6 events), then the calls: the fold's code
@@ -262,7 +265,7 @@ __device__ __forceinline__ void flush_pending(const MatchArgs &a, LaneState<W, S
             const uint32_t inv = sl >= 6 ? 1u : 0u, la = sl - 6 * inv;
 #pragma unroll
             for (uint32_t rk = 0; rk < (uint32_t)NP; ++rk) {
-                const uint32_t j = (uint32_t)(ord >> (4 * rk)) & 15u;
+                const uint32_t j = ord_at(rk);
                 const uint32_t meta = sel<NP>(s.p_meta, j);
                 if (rk < s.p_n && ((meta >> 8) & 1u) == inv && ((meta >> (PM_LM_SHIFT + la)) & 1u) && j != last) {
                     ev |= (uint64_t)j << (2 * nev); nev++; last = j;
@@ -282,7 +285,7 @@ __device__ __forceinline__ void flush_pending(const MatchArgs &a, LaneState<W, S
             const uint32_t inv = sl >= 6 ? 1u : 0u, la = sl - 6 * inv;
 #pragma unroll 1
             for (uint32_t rk = 0; rk < s.p_n; ++rk) {
-                const uint32_t j = (uint32_t)(ord >> (4 * rk)) & 15u;
+                const uint32_t j = ord_at(rk);
                 const uint32_t meta = sel<NP>(s.p_meta, j);
                 if (((meta >> 8) & 1u) == inv && ((meta >> (PM_LM_SHIFT + la)) & 1u) && j != last) {
                     deliver<W, SCORES, ALL>(a, s, sel<NP>(s.p_pos, j), meta, sel<NP>(sc, j));

@@ -389,19 +389,19 @@ def test_repeat_cliff_is_bit_exact_and_bounded_in_time(ora, seedl, kind, pb, sco
     m.close()
 
 
-@pytest.mark.parametrize("copies,kind", [(2, 3), (3, 3), (4, 3), (6, 3), (3, 2), (4, 0), (10, 3), (14, 3), (6, 0)])
+@pytest.mark.parametrize("copies,kind", [(2, 3), (3, 3), (4, 3), (6, 3), (3, 2), (4, 0), (10, 3), (14, 3), (22, 3), (30, 3), (6, 0)])
 def test_reads_on_few_copy_repeats_stay_with_the_lane_matcher(ora, copies, kind):
     """Exact copies of a 1 kbp segment (what a real genome is full of): every read on them has `copies` locations per
     strand, each reached through up to six lists.  Records, scores and counters are the oracle's; and up to four copies
     the reads are matched by the first pass of the lane-per-read kernel -- a window is queued once, a parked location is
-    recognised when it comes again (match_kernel.hip: queue_push, process_loaded).  Five to twelve copies are the second
-    pass' (bucket rows: the same kernel with twelve parked locations per lane), more than twelve the wave-per-read kernel's."""
+    recognised when it comes again (match_kernel.hip: queue_push, process_loaded).  Five to twenty-four copies are the second
+    pass' (bucket rows: the same kernel with twenty-four parked locations per lane), more the wave-per-read kernel's."""
     rng = np.random.default_rng(11 + copies)
     G = 300_000
     sym = rng.integers(0, 4, size=G, dtype=np.uint8)
     src = 10_000
     for c in range(copies - 1):
-        d = 40_000 + 18_000 * c
+        d = 40_000 + min(18_000, 250_000 // copies) * c
         sym[d:d + 1000] = sym[src:src + 1000]
     frag = np.array([0, G], dtype=np.uint64)
     reads = []
