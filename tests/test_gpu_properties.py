@@ -140,3 +140,41 @@ def test_fuzz_campaign_regressions():
                         "--only", "530", "568"], capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
     assert "568 configurations, 0 differ" in p.stdout
+
+
+def test_strand_symmetry_mid_size():
+    """A size-independent property: the reverse complement of a read (qualities reversed) aligns where the read does, on the
+    other strand, with the same mismatches and -- the FP64 sum runs over the same terms in the same order
+    (ComputeScore.hpp:50-190: the reversed read is scored as transposed[i] with quality[patl-1-i]) -- the same score bits.
+    The fold sees the strands in the other order, so a read whose record hangs on an epsilon-tie may change its state;
+    those are counted, not compared.  The genome holds 2..12-copy repeat families, so all three matchers take part."""
+    g = synth.random_genome(10_000_000, seed=71, n_frag=3, n_runs=30)
+    rng = np.random.default_rng(72)
+    for copies in (2, 3, 6, 12, 30):                      # families of exact copies of 800-base segments
+        for _ in range(25):
+            src = int(rng.integers(0, g.n - 800))
+            for _c in range(copies - 1):
+                d = int(rng.integers(0, g.n - 800))
+                g.sym[d:d + 800] = g.sym[src:src + 800]
+    b = synth.sample_reads(g, 200_000, 100, 0.02, seed=73, with_ids=False)
+    m = UniqueMatcher(_opts(24, 3, 1), table_kind=3, prefix_bits=20)       # bucket rows: 24-base seeds, 2^20 rows of 16 signature values, 9.5 entries per row
+    m.set_text_symbols(0, g.sym, g.frag_start)
+    m.build_index_block()
+    assert m.table_kind == 3
+    info, score = m.match_unique(b.bases, b.qual, patl=100)
+    c = m.counters()
+    assert c["handed_over"] > 100, c                                       # the second pass and the wave kernel have work
+    rb = np.ascontiguousarray((3 - np.minimum(b.bases, 3).reshape(-1, 100)[:, ::-1]).astype(np.uint8))
+    rb[b.bases.reshape(-1, 100)[:, ::-1] > 3] = 4
+    rq = np.ascontiguousarray(b.qual.reshape(-1, 100)[:, ::-1])
+    info_r, score_r = m.match_unique(rb.reshape(-1), rq.reshape(-1), patl=100)
+    st, fr, er, fi, po = unpack_info(info)
+    st2, fr2, er2, fi2, po2 = unpack_info(info_r)
+    both = ((st == 1) | (st == 2)) & ((st2 == 1) | (st2 == 2))
+    assert both.mean() > 0.7
+    assert np.array_equal(st[both] + st2[both], np.full(int(both.sum()), 3))          # Straight <-> Reverse
+    assert np.array_equal(po[both], po2[both]) and np.array_equal(er[both], er2[both]) and np.array_equal(fr[both], fr2[both])
+    assert np.array_equal(score[both].view(np.uint32), score_r[both].view(np.uint32))
+    changed = ((st == 4) != (st2 == 4)) | ((st == 0) != (st2 == 0))
+    assert changed.mean() < 0.002, changed.mean()
+    m.close()
