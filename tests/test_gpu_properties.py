@@ -146,8 +146,11 @@ def test_strand_symmetry_mid_size():
     """A size-independent property: the reverse complement of a read (qualities reversed) aligns where the read does, on the
     other strand, with the same mismatches and -- the FP64 sum runs over the same terms in the same order
     (ComputeScore.hpp:50-190: the reversed read is scored as transposed[i] with quality[patl-1-i]) -- the same score bits.
-    The fold sees the strands in the other order, so a read whose record hangs on an epsilon-tie may change its state;
-    those are counted, not compared.  The genome holds 2..12-copy repeat families, so all three matchers take part."""
+    WHETHER a location is found is not symmetric: the seed is the first seedl bases of the read as given (its reverse
+    complement for the other strand, SignatureConstruction.hpp:347-410), so the complemented read is seeded with what was
+    the read's tail, and a location whose mismatches crowd one end is found by one of the two only (0.5 % of the reads in
+    the oracle on this kind of input); and the fold sees the strands in the other order.  Those reads are counted, not
+    compared.  The genome holds 2..30-copy repeat families, so all three matchers take part."""
     g = synth.random_genome(10_000_000, seed=71, n_frag=3, n_runs=30)
     rng = np.random.default_rng(72)
     for copies in (2, 3, 6, 12, 30):                      # families of exact copies of 800-base segments
@@ -176,5 +179,5 @@ def test_strand_symmetry_mid_size():
     assert np.array_equal(po[both], po2[both]) and np.array_equal(er[both], er2[both]) and np.array_equal(fr[both], fr2[both])
     assert np.array_equal(score[both].view(np.uint32), score_r[both].view(np.uint32))
     changed = ((st == 4) != (st2 == 4)) | ((st == 0) != (st2 == 0))
-    assert changed.mean() < 0.002, changed.mean()
+    assert changed.mean() < 0.02, changed.mean()
     m.close()
