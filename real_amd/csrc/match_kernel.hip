@@ -83,6 +83,8 @@ __host__ __device__ constexpr uint32_t stg_bytes2() { return MQR2 * 64u * 5u + 6
 #define SLOT_BIG 30u   // cslot of a read that is handed over because of a long equal range (not for want of room: the second pass would be no help)
 #define PEND_OVF 0xffu // p_n of a read that is handed over to the wave-cooperative matcher (match_wave.hip)
 #define BIG_T 48u      // an equal range / bucket scan longer than this many entries is not walked by one lane: hand-over
+#define BIG_T2 1024u   // ... of the second pass: its waves hold handed-over reads only, and a long range whose entries nearly all fail the
+                       // partner filter (a skewed base composition is full of them) is cheap to walk sixteen entries per round trip
 
 // bits 9..14 of a parked location's meta word: the lists whose update() call it has had
 #define PM_LM_SHIFT 9
@@ -119,12 +121,15 @@ struct LaneState {
     // work counters of this read, packed (a register each would cost six of the 168): cA = L:4 | V:12 | S:12, cB = P:11 | C:11 | H:10.
     // No field overflows without the read being handed over -- a lane walks at most BIG_T entries of each of its 12 equal
     // ranges (plus a binary search) -- and a read that is handed over counts for nothing here (the wave matcher counts it).
-    unsigned cA, cB;
+    // (the second pass walks up to BIG_T2 entries per range: P and C get words of their own there)
+    unsigned cA, cB, cPw, cCw;
     __device__ __forceinline__ void addL(unsigned n) { cA += n; }
     __device__ __forceinline__ void addV(unsigned n) { cA += n << 4; }
     __device__ __forceinline__ void addS(unsigned n) { cA += n << 16; }
-    __device__ __forceinline__ void addP(unsigned n) { cB += n; }
-    __device__ __forceinline__ void addC(unsigned n) { cB += n << 11; }
+    __device__ __forceinline__ void addP(unsigned n) { if (NP > NPEND) cPw += n; else cB += n; }
+    __device__ __forceinline__ void addC(unsigned n) { if (NP > NPEND) cCw += n; else cB += n << 11; }
+    __device__ __forceinline__ unsigned getP() const { return NP > NPEND ? cPw : (cB & 2047u); }
+    __device__ __forceinline__ unsigned getC() const { return NP > NPEND ? cCw : ((cB >> 11) & 2047u); }
     __device__ __forceinline__ void addH(unsigned n) { cB += n << 22; }
 #if RH_PHASE_TIMING
     unsigned tW, tD, tR; // ticks of 10 ns this wave spent waiting for rows, decoding them, draining its queues
@@ -797,6 +802,8 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
     // (queue slots per lane and strand, and where the rows lie behind the queue: the first pass' or the second's)
     constexpr uint32_t MQRn = NP == NPEND ? MQR : MQR2, ROWBUF_OFFn = MQRn * 64u * 5u, BKX_OFFn = ROWBUF_OFFn + 64u * 128u;
     constexpr bool has_pass2_rows = SCORES || ALL; // (bucket rows with parked hits: a second pass stands behind the first)
+    constexpr uint32_t BIGn = NP == NPEND ? BIG_T : BIG_T2; // entries of one equal range a lane walks
+    constexpr uint32_t OVN = NP == NPEND ? 4u : 16u;         // overflow entries of a complex row requested together
     constexpr int NL = LA1 - LA0;
     uint32_t lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane)); // (not to be carried across the tile loop of the kernel)
@@ -971,7 +978,9 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
             }
             if (!wide) s.addC(e_cnt); // (wide: counted when the text confirms the membership)
             s.addP(e_cnt);
-            if (e_cnt > BIG_T) { s.p_n = PEND_OVF; s.cslot = SLOT_BIG; e_cnt = 0; } // a long equal range is walked by a whole wave (match_wave.hip)
+            // a long equal range is not walked by a lane of the first pass (it would hold its wave): the second pass takes it up to
+            // BIG_T2 entries, beyond that a whole wave does (match_wave.hip)
+            if (e_cnt > BIGn) { s.p_n = PEND_OVF; s.cslot = (NP == NPEND && has_pass2_rows && DEFER && e_cnt <= BIG_T2) ? SLOT_NONE : SLOT_BIG; e_cnt = 0; }
             if (RH_ABLATE & 4) e_cnt = 0;
         }
         const uint32_t rk = wide ? rh_fp16(r) : (r >> (pbits - p16)); // what the 16 key bits of a row entry are compared with
@@ -1038,7 +1047,7 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
             take(step, (h & 1) ? d1 : ((d0 >> 16) | (d1 << 16)));
         }
         // complex rows: {key, pos} in the overflow array.  The first two entries are there (requested above); the rest comes
-        // four at a time, their loads in flight together -- one round trip per four entries, not one per entry
+        // OVN at a time (four; sixteen in the second pass), their loads in flight together -- one round trip per OVN entries, not one per entry
         auto take_ovf = [&](bool ok, uint2 e) { take(ok && passes(wide ? (e.x ^ r) : ((e.x & pmask) ^ r)), e.y); };
         if (__any(e_ovf && e_cnt)) {
             take_ovf(e_ovf && e_cnt > 0, make_uint2((uint32_t)pre.a, (uint32_t)(pre.a >> 32)));
@@ -1046,12 +1055,12 @@ __device__ __forceinline__ void match_lists_rows(const MatchArgs &a, LaneState<W
         }
         e_j = 2;
         while (__any(e_ovf && e_j < e_cnt)) {
-            uint2 e[4];
+            uint2 e[OVN];
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) e[u] = (e_ovf && e_j + u < e_cnt) ? a.ix.ent[la][e_base + e_j + u] : make_uint2(0u, 0u);
+            for (uint32_t u = 0; u < OVN; ++u) e[u] = (e_ovf && e_j + u < e_cnt) ? a.ix.ent[la][e_base + e_j + u] : make_uint2(0u, 0u);
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) take_ovf(e_ovf && e_j + u < e_cnt, e[u]);
-            e_j += 4;
+            for (uint32_t u = 0; u < OVN; ++u) take_ovf(e_ovf && e_j + u < e_cnt, e[u]);
+            e_j += OVN;
         }
 #if RH_PHASE_TIMING
         s.tD += PH_NOW() - ph1;
@@ -1215,7 +1224,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PASS2 ? 2 :
     uint8_t *q_la = stg + MQ * 64 * 4 + lane;
     const unsigned ph_start = PH_NOW();
     LaneState<W, SCORES, ALL, NP> s;
-    s.cA = s.cB = 0;
+    s.cA = s.cB = s.cPw = s.cCw = 0;
 #if RH_PHASE_TIMING
     s.tW = s.tD = s.tR = 0;
     unsigned tQ = 0, tS = 0;
@@ -1303,7 +1312,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PASS2 ? 2 :
             const unsigned long long slot = wave_append_slot(a.ovf_count);
             a.ovf_list[slot] = (uint32_t)r;
         }
-        s.cA = s.cB = 0;
+        s.cA = s.cB = s.cPw = s.cCw = 0;
     }
     // ---- qualities: global -> LDS; score the parked hits and deliver them
     const uint8_t *qsrc_ = nullptr;
@@ -1375,7 +1384,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PASS2 ? 2 :
     constexpr int NC = 8;
 #else
     // ([7]: reads matched outside the first pass -- real_hip_counters.handed_over)
-    unsigned c[8] = {cR, s.cA & 15u, s.cB & 2047u, (s.cB >> 11) & 2047u, s.cA >> 16, s.cB >> 22, (s.cA >> 4) & 4095u, PASS2 ? cR : 0u};
+    unsigned c[8] = {cR, s.cA & 15u, s.getP(), s.getC(), s.cA >> 16, s.cB >> 22, (s.cA >> 4) & 4095u, PASS2 ? cR : 0u};
     constexpr int NC = PASS2 ? 8 : 7;
     (void)ph_start; (void)ph_front;
 #endif
