@@ -292,7 +292,8 @@ typedef struct real_hip_counters {
     uint64_t seedpass;    /* S  candidates with seedk <= seedkmax                     */
     uint64_t hits;        /* H  updater::update calls                                 */
     uint64_t verified;    /* distinct (read,strand,pos) actually verified on text     */
-    uint64_t handed_over; /* reads (among R) matched by the wave-cooperative kernel: long equal ranges / many hits */
+    uint64_t handed_over; /* reads (among R) the first pass of the lane matcher did not finish itself: matched by its second
+                             pass (many locations, long equal ranges) or by the wave-per-read kernel */
 } real_hip_counters;
 int real_hip_counters_get(real_hip_ctx *ctx, real_hip_counters *out, int reset);
 
