@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=300)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--copy-prob", type=float, default=0.3, help="share of the configurations whose genome holds exact copies of a segment")
+    ap.add_argument("--skew-prob", type=float, default=0.2, help="share of the configurations whose genome has 70 .. 95 %% A+T (equal ranges of tens to hundreds of entries)")
     ap.add_argument("--diverged-prob", type=float, default=0.3, help="share of the uniform-length configurations whose reads have planted near-copies "
                     "(1-2 substitutions in chosen seed segments, low qualities there): the class on which the order of the update() calls decides")
     ap.add_argument("--only", type=int, nargs="*", default=[], help="run only these iterations of the seed (the others are generated and skipped) and say what differs")
@@ -49,6 +50,11 @@ def main():
         repeats = int(rng.choice([0, 5, 40]))
         g = synth.random_genome(n, seed=int(rng.integers(1 << 30)), n_frag=int(rng.choice([1, 2, 7])), n_runs=int(rng.choice([0, 3, 20])),
                                 repeats=repeats, repeat_len=int(rng.choice([150, 400, 1200])))
+        if rng.random() < args.skew_prob:  # a skewed base composition: long equal ranges whose entries nearly all fail the partner filter
+            at = float(rng.choice([0.7, 0.85, 0.95]))
+            keep_n = g.sym > 3
+            g.sym[:] = rng.choice(np.array([0, 1, 2, 3], dtype=np.uint8), size=g.n, p=[at / 2, (1 - at) / 2, (1 - at) / 2, at / 2])
+            g.sym[keep_n] = 4
         if rng.random() < args.copy_prob:  # exact copies of a segment: reads on them have several locations
             L = int(min(rng.choice([300, 1000]), n // 8))
             src = int(rng.integers(0, n - L))
