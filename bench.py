@@ -259,7 +259,7 @@ class CpuSide:
 # ---------------------------------------------------------------------------------------------
 # timed loops
 # ---------------------------------------------------------------------------------------------
-def timed_unique(torch, dist, m, rlib, bases, qual, patl, n, steps, warmup, world, rank, dev, gather_dev, log=None, packed=False):
+def timed_unique(torch, dist, m, rlib, bases, qual, patl, n, steps, warmup, world, rank, dev, gather_dev, log=None, packed=False, fresh=False):
     """K steps of matchUnique over the resident batch, bracketed by barrier + synchronize on both sides, MAX over
     ranks.  N > 1: the records of step k travel to the root while step k+1 is matched (two alternating record
     buffers).  Returns (seconds, counters, (match_ms, launches), (repeat_ms, launches), last (info, score))."""
@@ -286,8 +286,10 @@ def timed_unique(torch, dist, m, rlib, bases, qual, patl, n, steps, warmup, worl
             if gather_dev != "cpu":
                 torch.cuda.current_stream().synchronize()       # (an RCCL wait only holds the stream: make the host see it)
             exposed[0] += time.perf_counter() - tw
-        bi.zero_(); bs.fill_(NO_SCORE)                          # uniqueinfo(numpat): state NoMatch, score -FLT_MAX
-        m.match_unique(bases, qual, patl=patl, info=bi, score=bs, n_reads=n, packed=packed)
+        if not fresh:
+            bi.zero_(); bs.fill_(NO_SCORE)                      # uniqueinfo(numpat): state NoMatch, score -FLT_MAX
+        # (fresh: real_hip_batch.fresh -- the matcher starts every record itself, the arrays are outputs only)
+        m.match_unique(bases, qual, patl=patl, info=bi, score=bs, n_reads=n, packed=packed, fresh=fresh)
         if rg is not None:                                      # the one collective: records to the root
             if gather_dev == "cpu":
                 rg.start(slot, bi.cpu(), bs.cpu())
@@ -671,6 +673,22 @@ def extras(torch, dist, rlib, args, m, opts, cpu, sym, sym_host, frag, reads, n,
         log("extra: %s bases %.1f ms/step" % ("packed" if other_packed else "byte", dt / K * 1e3))
     except Exception as e:
         ex["c2_other_input_format"] = {"error": repr(e)}
+
+    # (0b) the headline's step with the records started by the matcher itself (real_hip_batch.fresh, what the `real` driver does for
+    # the first genome block): no initialisation pass over the record arrays, and the kernel does not read them
+    try:
+        hb = pk if pk is not None else bases
+        dt, ctr, (ms, ln), (rms, rn), (fi, fs) = timed_unique(torch, dist, m, rlib, hb, qual, patl, n, K, 1, 1, 0, dev, dev, packed=pk is not None, fresh=True)
+        ref_i = torch.zeros(n, dtype=torch.int64, device=dev)
+        ref_s = torch.full((n,), NO_SCORE, dtype=torch.float32, device=dev)
+        m.match_unique(hb, qual, patl=patl, info=ref_i, score=ref_s, n_reads=n, packed=pk is not None)
+        ex["c2_fresh_records"] = {"ms_per_step": dt / K * 1e3, "reads_per_s": n * K / dt, "avg_match_kernel_ms": ms / max(ln, 1),
+                                  "records_equal_initialised_run": bool(torch.equal(fi, ref_i) and torch.equal(fs.view(torch.int32), ref_s.view(torch.int32))),
+                                  "note": "real_hip_batch.fresh = 1: the record arrays are outputs only (the headline initialises them every step and the kernel reads them)"}
+        del fi, fs, ref_i, ref_s
+        log("extra: fresh records %.1f ms/step" % (dt / K * 1e3))
+    except Exception as e:
+        ex["c2_fresh_records"] = {"error": repr(e)}
 
     # (1) the same step on the same reads in shuffled order (a sequencer does not sort; genpat does)
     try:
